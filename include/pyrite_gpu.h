@@ -1,0 +1,355 @@
+/*
+ * pyrite_gpu.h -- C ABI of the MI355X-native replacement for Pyrite's camera-to-light
+ * ("simple") renderer hot path.
+ *
+ * The reference (Ogeon/pyrite) has no FFI; the seam this ABI drops in behind is
+ *
+ *     Renderer::render(&self, film, task_runner, on_status, camera, world, resources)
+ *         pyrite/src/renderer/mod.rs:77-111   (match Algorithm::Simple => simple::render, :87-89)
+ *
+ * i.e. everything the reference does from `simple::render` (pyrite/src/renderer/simple.rs:17-56)
+ * downwards. A Rust caller binds these symbols with an `extern "C"` block
+ * and calls them from a new `Algorithm::Gpu` arm.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++ / torch / HIP types in any signature
+ *     (`hip_stream` is an opaque `void*` holding a hipStream_t, NULL = default stream);
+ *   - the caller owns every input array and the film buffer; the library copies what it needs in
+ *     pyr_scene_create and owns the returned PyrScene;
+ *   - every function returns PYR_OK (0) or a negative PyrStatus and never aborts the process
+ *     (the reference panics with panic=abort: Cargo.toml:6,10); pyr_last_error() returns a
+ *     thread-local message for the last failure;
+ *   - all floating point data is IEEE binary32, matrices are column-major (cgmath::Matrix4);
+ *   - progress callbacks are only ever invoked on the calling thread
+ *     (FnMut, not Send: pyrite/src/renderer/mod.rs:181-183).
+ */
+#ifndef PYRITE_GPU_H
+#define PYRITE_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYR_ABI_VERSION 1
+
+typedef enum PyrStatus {
+    PYR_OK = 0,
+    PYR_ERR_INVALID_ARGUMENT = -1,
+    PYR_ERR_UNSUPPORTED = -2, /* texture / normal-map opcodes, ray-marched shapes: SURVEY.md section 8 "out" rows */
+    PYR_ERR_DEVICE = -3,      /* a HIP call failed or no gfx950 device is present */
+    PYR_ERR_OUT_OF_MEMORY = -4
+} PyrStatus;
+
+/* ---------------------------------------------------------------- film ------------------------ */
+
+/* == GrainData {accumulator, weight}: pyrite/src/film.rs:165-169 (field order acc, weight). */
+typedef struct PyrGrain {
+    float acc;
+    float weight;
+} PyrGrain;
+
+/* == Film {width, height, grains_per_pixel, wavelength_start, wavelength_width}: film.rs:9-18.
+ * Grain index = (x + y*width)*bins + bin  (film.rs:56). */
+typedef struct PyrFilmDesc {
+    uint32_t width;
+    uint32_t height;
+    uint32_t bins;
+    float wl_start; /* 380 by default: renderer/mod.rs:16 */
+    float wl_width; /* 400 by default */
+} PyrFilmDesc;
+
+/* ---------------------------------------------------------------- renderer parameters --------- */
+
+#define PYR_FLAG_COUNTERS 1u /* run the instrumented kernel build and fill PyrCounters */
+
+/* == Renderer {bounces, pixel_samples, light_samples, spectrum_samples, tile_size}
+ * (renderer/mod.rs:18-28; defaults :63-75: 8 / - / 4 / 10 / 32). `threads` has no meaning here.
+ *
+ * The reference seeds one entropy RNG per tile (simple.rs:26-28) and is not reproducible; here
+ * every sample (tile, iteration) owns a xorshift128 stream seeded from (seed, tile, iteration), see
+ * DESIGN.md "RNG". `seed` selects the run.
+ *
+ * Sharding: a call renders the raster-order tile range [tile_begin, tile_end) (tile index
+ * ty*tiles_x + tx over the grid of make_tiles, renderer/algorithm.rs:152-188); tile_end == 0 means
+ * "all tiles". The film buffer handed to the call covers pixel rows
+ * [film_row_begin, film_row_begin + film_row_count) of the image (film_row_count == 0 means the whole
+ * image); exposures that map outside that window are dropped exactly like exposures outside the
+ * image (film.rs:51-54,92). Multi-GPU hosts give each rank a tile range and a row window (plus a
+ * one-row halo) and gather the windows. */
+typedef struct PyrRenderParams {
+    uint32_t bounces;
+    uint32_t pixel_samples;
+    uint32_t light_samples;
+    uint32_t spectrum_samples;
+    uint32_t tile_size;
+    uint32_t flags;
+    uint64_t seed;
+    uint32_t tile_begin;
+    uint32_t tile_end;
+    uint32_t film_row_begin;
+    uint32_t film_row_count;
+} PyrRenderParams;
+
+/* == Camera::Perspective {transform, view_plane, focus_distance, aperture}: cameras.rs:20-27.
+ * cam_to_world = look_at(from,to,up)^-1 (project/mod.rs:257-266), column-major.
+ * view_plane = cos(fov/2)/sin(fov/2), fov in degrees (cameras.rs:43-45). */
+typedef struct PyrCamera {
+    float cam_to_world[16];
+    float view_plane;
+    float focus_distance;
+    float aperture;
+} PyrCamera;
+
+/* ---------------------------------------------------------------- programs (the expression VM) */
+
+/* Flattened form of Instruction / InstructionType (program/instruction.rs:12-119). */
+typedef enum PyrOp {
+    PYR_OP_NUMBER = 0,        /* NumberValue     {number=x.constant, output}                 :20-23 */
+    PYR_OP_VECTOR = 1,        /* VectorValue     {x,y,z,w, output}                           :24-30 */
+    PYR_OP_RGB = 2,           /* RgbValue        {red=x, green=y, blue=z, output}            :31-36 */
+    PYR_OP_SPECTRUM = 3,      /* SpectrumValue   {wavelength=x, spectrum=a, output}          :37-41 */
+    PYR_OP_COLOR_TEXTURE = 4, /* ColorTextureValue -- PYR_ERR_UNSUPPORTED                    :42-46 */
+    PYR_OP_MONO_TEXTURE = 5,  /* MonoTextureValue  -- PYR_ERR_UNSUPPORTED                    :47-51 */
+    PYR_OP_RGB_SPECTRUM = 6,  /* RgbSpectrumValue{wavelength=x, source=a (rgb reg), output}  :52-56 */
+    PYR_OP_FRESNEL = 7,       /* Fresnel {ior=x, env_ior=y, normal=a, incident=b (vector inputs), output} :57-63 */
+    PYR_OP_BLACKBODY = 8,     /* Blackbody {wavelength=x, temperature=y, output}             :64-68 */
+    PYR_OP_RGB_TO_VECTOR = 9, /* Convert::RgbToVector {source=a, output}                     :69-71,104-110 */
+    PYR_OP_BINARY = 10,       /* Binary {value_type, operator, lhs=a, rhs=b, output}         :72-78 */
+    PYR_OP_MIX = 11,          /* Mix {value_type, lhs=a, rhs=b, amount=x, output}            :79-85 */
+    PYR_OP_CLAMP = 12         /* Clamp {value=x, min=y, max=z, output}                       :86-91 */
+} PyrOp;
+
+typedef enum PyrValueType { PYR_VT_NUMBER = 0, PYR_VT_VECTOR = 1, PYR_VT_RGB = 2 } PyrValueType; /* :112-118 */
+typedef enum PyrBinaryOperator { PYR_BIN_ADD = 0, PYR_BIN_SUB = 1, PYR_BIN_MUL = 2, PYR_BIN_DIV = 3 } PyrBinaryOperator;
+
+/* NumberValue<N> (instruction.rs:94-99). */
+typedef enum PyrOperandKind { PYR_OPERAND_CONSTANT = 0, PYR_OPERAND_INPUT = 1, PYR_OPERAND_REGISTER = 2 } PyrOperandKind;
+typedef enum PyrNumberInput { PYR_INPUT_WAVELENGTH = 0 } PyrNumberInput;                 /* program/mod.rs:117-120 */
+typedef enum PyrVectorInput { PYR_INPUT_NORMAL = 0, PYR_INPUT_INCIDENT = 1, PYR_INPUT_TEXTURE = 2 } PyrVectorInput; /* :130-135 */
+
+/* Inputs bitflags (program/mod.rs:150-159). */
+#define PYR_DEP_WAVELENGTH 0x01u
+#define PYR_DEP_NORMAL 0x10u
+#define PYR_DEP_INCIDENT 0x20u
+#define PYR_DEP_TEXTURE 0x40u
+
+typedef struct PyrOperand {
+    uint32_t kind; /* PyrOperandKind */
+    uint32_t bits; /* CONSTANT: the f32 bit pattern; INPUT: PyrNumberInput; REGISTER: number register */
+} PyrOperand;
+
+typedef struct PyrInstr {
+    uint32_t op;         /* PyrOp */
+    uint32_t value_type; /* PyrValueType, BINARY / MIX only */
+    uint32_t operator_;  /* PyrBinaryOperator, BINARY only */
+    uint32_t deps;       /* Instruction::dependencies (instruction.rs:15) */
+    uint32_t output;     /* register index; the register file follows from op / value_type */
+    uint32_t a;
+    uint32_t b;
+    uint32_t reserved;
+    PyrOperand x, y, z, w;
+} PyrInstr; /* 64 bytes */
+
+#define PYR_MAX_NUMBER_REGISTERS 16
+#define PYR_MAX_VECTOR_REGISTERS 4
+#define PYR_MAX_RGB_REGISTERS 4
+
+/* ProgramType (program/mod.rs:61-73): Constant short-circuits, Instructions reads one output register. */
+typedef enum PyrProgramKind { PYR_PROGRAM_CONSTANT = 0, PYR_PROGRAM_INSTRUCTIONS = 1 } PyrProgramKind;
+typedef enum PyrProgramOutput { PYR_OUTPUT_NUMBER = 0, PYR_OUTPUT_VECTOR = 1 } PyrProgramOutput; /* mod.rs:103-106 */
+
+typedef struct PyrProgram {
+    uint32_t kind;        /* PyrProgramKind */
+    float constant;       /* value of a Constant program */
+    uint32_t first_instr; /* into PyrSceneDesc::instrs */
+    uint32_t num_instrs;
+    uint32_t output_kind; /* PyrProgramOutput */
+    uint32_t output_reg;
+    uint32_t num_numbers; /* register counts: program/mod.rs:67-71 */
+    uint32_t num_vectors;
+    uint32_t num_rgbs;
+} PyrProgram;
+
+/* Spectrum<f32> (project/spectra.rs:13-24). ARRAY: `count` samples evenly spaced over [min,max],
+ * clamped to the end values outside (spectra.rs:32-55). CURVE: `count` (x,y) pairs (2*count floats),
+ * zero at and outside the end points (math.rs:22-72). Data lives at spectrum_data[offset...]. */
+typedef enum PyrSpectrumFormat { PYR_SPECTRUM_ARRAY = 0, PYR_SPECTRUM_CURVE = 1 } PyrSpectrumFormat;
+typedef struct PyrSpectrum {
+    uint32_t format;
+    float min;
+    float max;
+    uint32_t offset;
+    uint32_t count;
+} PyrSpectrum;
+
+/* ---------------------------------------------------------------- materials ------------------- */
+
+/* SurfaceBsdfType (materials/mod.rs:336-342). */
+typedef enum PyrBsdf { PYR_BSDF_EMISSIVE = 0, PYR_BSDF_DIFFUSE = 1, PYR_BSDF_MIRROR = 2, PYR_BSDF_REFRACTIVE = 3 } PyrBsdf;
+
+/* MaterialComponent (materials/mod.rs:230-235) + refractive::Properties (refractive.rs:39-45). */
+typedef struct PyrComponent {
+    uint32_t bsdf;                /* PyrBsdf */
+    uint32_t color_program;       /* SurfaceBsdf::color */
+    int32_t probability_program;  /* -1 = None */
+    float selection_compensation; /* = number of entries in the list this component belongs to (mod.rs:213-221) */
+    float ior, env_ior, dispersion, env_dispersion;
+} PyrComponent;
+
+/* Material {surface{components, emissive}, normal_map} (materials/mod.rs:27-31, :83-87). The emissive
+ * list holds its own copies (with their own selection_compensation) of the emissive components. */
+typedef struct PyrMaterial {
+    uint32_t first_component;
+    uint32_t num_components;
+    uint32_t first_emissive;
+    uint32_t num_emissive;
+    int32_t normal_map_program; /* -1 = None; anything else is PYR_ERR_UNSUPPORTED in this round */
+} PyrMaterial;
+
+/* Lamp (lamp.rs:12-20). */
+typedef enum PyrLampKind { PYR_LAMP_DIRECTIONAL = 0, PYR_LAMP_POINT = 1, PYR_LAMP_SHAPE = 2 } PyrLampKind;
+typedef enum PyrShapeKind { PYR_SHAPE_SPHERE = 0, PYR_SHAPE_TRIANGLE = 1, PYR_SHAPE_PLANE = 2 } PyrShapeKind;
+typedef struct PyrLamp {
+    uint32_t kind;          /* PyrLampKind */
+    uint32_t shape_kind;    /* SHAPE: PyrShapeKind (sphere or triangle) */
+    uint32_t shape_index;   /* SHAPE: index into the sphere / triangle arrays */
+    uint32_t color_program; /* DIRECTIONAL / POINT */
+    float v[3];             /* DIRECTIONAL: direction (as given, not normalised); POINT: position */
+    float width;            /* DIRECTIONAL: cosine of the half angle (lamp.rs:30-34, tracer.rs:452) */
+} PyrLamp;
+
+/* ---------------------------------------------------------------- the scene ------------------- */
+
+/* World {sky, lights, planes, finite_objects} (world.rs:31-36) + Resources.spectra (program/mod.rs:144-148),
+ * after World::from_project (world.rs:39-271) has applied mesh scale and transform. */
+typedef struct PyrSceneDesc {
+    /* Shape::Triangle (shapes/mod.rs:39-46): v1,v2,v3 positions, unit vertex normals, uvs. */
+    uint32_t num_triangles;
+    const float* tri_positions;   /* [num_triangles][3][3] */
+    const float* tri_normals;     /* [num_triangles][3][3] */
+    const float* tri_uvs;         /* [num_triangles][3][2] or NULL (all zero) */
+    const uint32_t* tri_material; /* [num_triangles] */
+
+    /* Shape::Sphere (shapes/mod.rs:33-38). */
+    uint32_t num_spheres;
+    const float* spheres;           /* [num_spheres][4] = centre xyz, radius */
+    const float* sphere_tex_scale;  /* [num_spheres][2] or NULL (1,1) */
+    const uint32_t* sphere_material;
+
+    /* shapes::Plane (shapes/mod.rs:434-439): point on the plane, unit normal, texture scale. */
+    uint32_t num_planes;
+    const float* planes; /* [num_planes][8] = origin xyz, normal xyz, texture_scale xy */
+    const uint32_t* plane_material;
+
+    uint32_t num_lamps;
+    const PyrLamp* lamps; /* order == World::lights, pick_lamp indexes it (world.rs:301-305) */
+
+    uint32_t num_materials;
+    const PyrMaterial* materials;
+    uint32_t num_components;
+    const PyrComponent* components;
+
+    uint32_t num_programs;
+    const PyrProgram* programs;
+    uint32_t num_instrs;
+    const PyrInstr* instrs;
+
+    uint32_t num_spectra;
+    const PyrSpectrum* spectra;
+    uint32_t num_spectrum_floats;
+    const float* spectrum_data;
+
+    /* crate::rgb::response::RGB (build.rs:18-59): `rgb_basis_count` rows of (r,g,b), an ARRAY spectrum over
+     * [rgb_basis_min, rgb_basis_max]. NULL unless a program holds PYR_OP_RGB_SPECTRUM. */
+    const float* rgb_basis;
+    uint32_t rgb_basis_count;
+    float rgb_basis_min;
+    float rgb_basis_max;
+
+    uint32_t sky_program; /* World::sky */
+} PyrSceneDesc;
+
+typedef struct PyrScene PyrScene;
+
+/* == Progress {progress: u8, message} (renderer/mod.rs:229-232). */
+typedef void (*PyrProgressFn)(void* user, uint8_t percent, const char* message);
+
+/* Work counters of one render (flags & PYR_FLAG_COUNTERS) -- the units SURVEY.md section 8(d) prices. */
+typedef struct PyrCounters {
+    uint64_t samples;         /* iterations of the simple.rs:78 loop */
+    uint64_t extension_rays;  /* World::intersect calls from tracer.rs:222 */
+    uint64_t shadow_rays;     /* World::intersect calls from tracer.rs:381 */
+    uint64_t box_tests;       /* AABBs slab-tested (32 B each) */
+    uint64_t triangle_tests;  /* Moeller-Trumbore tests (36 B each) */
+    uint64_t sphere_tests;    /* 16 B each */
+    uint64_t plane_tests;     /* 16 B each */
+    uint64_t shaded_hits;     /* surface-data fetches (52 B each) */
+    uint64_t exposures;       /* Film::expose calls that landed in the window (16 B each) */
+} PyrCounters;
+
+/* One closest-hit result of pyr_scene_intersect: == Intersection {distance, surface_point} (shapes/mod.rs:472-482). */
+#define PYR_HIT_NONE 0xFFFFFFFFu
+typedef struct PyrHit {
+    float distance;
+    uint32_t shape; /* PYR_HIT_NONE, or (PyrShapeKind << 30) | index */
+    float u, v;     /* triangle barycentrics (ShapeSurfacePoint::Triangle {u, v}), else 0 */
+} PyrHit;
+
+/* ---------------------------------------------------------------- entry points ---------------- */
+
+int pyr_abi_version(void);
+
+/* Number of gfx950 devices visible to the process (0 if none; never fails). */
+int pyr_device_count(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* pyr_last_error(void);
+
+/* Replaces the part of World::from_project that builds the acceleration structure
+ * (Bvh::new, world.rs:262 / spatial/bvh.rs:13-155) and freezes the scene: copies the description, builds the
+ * BVH on the host, uploads everything to `device`. */
+int pyr_scene_create(const PyrSceneDesc* desc, int device, PyrScene** out_scene);
+void pyr_scene_destroy(PyrScene* scene);
+
+/* Replaces Renderer::render / simple::render (renderer/mod.rs:77-111, renderer/simple.rs:17-56) for
+ * Algorithm::Simple. Blocking. Adds the exposures of this call into `film_inout`, a HOST buffer of
+ * (film_row_count or height) * width * bins grains in the film.rs:56 layout. `on_status` may be NULL. */
+int pyr_render_simple(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* params,
+                      PyrGrain* film_inout, PyrProgressFn on_status, void* user);
+
+/* Same, but `film_device` is DEVICE memory on the scene's device and the work is enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream) without synchronising: the caller synchronises the stream. */
+int pyr_render_simple_device(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film,
+                             const PyrRenderParams* params, PyrGrain* film_device, void* hip_stream);
+
+/* Counters of the last render on this scene that ran with PYR_FLAG_COUNTERS (synchronises the device). */
+int pyr_scene_counters(PyrScene* scene, PyrCounters* out);
+
+/* World::intersect (world.rs:273-299) for a batch of rays: rays = [n][6] (origin xyz, direction xyz), HOST memory;
+ * hits = [n], HOST memory. `elapsed_ms`, if not NULL, receives the kernel's duration measured with HIP events;
+ * `counters`, if not NULL, receives box/triangle/sphere/plane test counts for the batch (instrumented build). */
+int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* hits, float* elapsed_ms,
+                        PyrCounters* counters);
+
+/* Same for rays and hits already resident on the device, enqueued on `hip_stream` without synchronising. */
+int pyr_scene_intersect_device(PyrScene* scene, const float* rays_device, uint32_t n, PyrHit* hits_device,
+                               void* hip_stream);
+
+/* Introspection of the acceleration structure the library built (node count, bytes, depth). */
+typedef struct PyrBvhInfo {
+    uint32_t num_nodes;   /* 64-byte two-child nodes */
+    uint32_t num_leaves;
+    uint32_t max_depth;
+    uint32_t num_primitives;
+    uint64_t node_bytes;
+    uint64_t primitive_bytes;
+} PyrBvhInfo;
+int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PYRITE_GPU_H */

@@ -1,0 +1,37 @@
+"""Loader for the C-ABI library (pyrite_amd/csrc/libpyrite_gpu.so).
+
+There is no CPU fallback: if the library is missing or a symbol is absent this raises, loudly. The library is
+built in-tree by `__graft_entry__.build()` / `python -m pyrite_amd.build`."""
+import ctypes
+import os
+
+from . import abi
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpyrite_gpu.so")
+_lib = None
+
+
+class PyriteGpuError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("pyrite_gpu error %d: %s" % (status, message))
+        self.status = status
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "pyrite_amd has no CPU fallback." % LIB_PATH
+            )
+        _lib = abi.bind(ctypes.CDLL(LIB_PATH))
+        version = _lib.pyr_abi_version()
+        if version != abi.PYR_ABI_VERSION:
+            raise ImportError("libpyrite_gpu.so has ABI version %d, python side expects %d" % (version, abi.PYR_ABI_VERSION))
+    return _lib
+
+
+def check(status):
+    if status != abi.PYR_OK:
+        raise PyriteGpuError(status, lib().pyr_last_error().decode("utf-8", "replace"))

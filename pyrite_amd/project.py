@@ -1,0 +1,175 @@
+"""Host-side mirror of Pyrite's project operator surface.
+
+The reference describes a scene as a Lua script whose prelude (pyrite/src/project/lib.lua:1-309) builds plain
+tables that `typed_nodes::FromLua` turns into the typed tree of pyrite/src/project/mod.rs:103-252. No Lua
+interpreter exists in this image, so the same surface is offered as Python callables with the same names,
+argument keys and defaults; the objects they build are the typed tree. `compiler.py` lowers that tree exactly
+as World::from_project / Material::from_project / ProgramCompiler do.
+
+    from pyrite_amd.project import *
+    light = {"surface": material.emissive(color=lamp * 3) + material.diffuse(color=0.78)}
+    project = {"image": {...}, "renderer": renderer.simple(pixel_samples=64), "camera": camera.perspective(...),
+               "world": {"objects": [shape.sphere(position=vector(0, 1, 2), radius=1, material=light)]}}
+"""
+from __future__ import annotations
+
+import copy
+from types import SimpleNamespace
+
+__all__ = [
+    "Expr", "Material", "Node", "vector", "rgb", "spectrum", "blackbody", "fresnel", "mix", "texture", "light_source",
+    "material", "shape", "light", "transform", "camera", "renderer", "bounds", "ray_marched",
+]
+
+
+class Node:
+    """A Lua table with a `type` tag (lib.lua `_pyrite.make_basic`); supports :clone() / :with{}."""
+
+    def __init__(self, type_, **props):
+        self.type = type_
+        self.props = props
+
+    def __getattr__(self, key):
+        try:
+            return self.__dict__["props"][key]
+        except KeyError:
+            raise AttributeError(key)
+
+    def get(self, key, default=None):
+        return self.props.get(key, default)
+
+    def clone(self):  # lib.lua:44-56, shallow
+        c = copy.copy(self)
+        c.props = dict(self.props)
+        return c
+
+    def with_(self, **changes):  # lib.lua:59-74 (`with` is a Python keyword)
+        c = self.clone()
+        c.props.update(changes)
+        return c
+
+    def __repr__(self):
+        return "%s(%s)" % (self.type, ", ".join("%s=%r" % kv for kv in self.props.items()))
+
+
+class Expr(Node):
+    """ComplexExpression (project/expressions.rs:163-201). Plain Python numbers are Expression::Number."""
+
+    def _bin(self, op, lhs, rhs):
+        return Expr("binary", operator=op, lhs=lhs, rhs=rhs)  # lib.lua:2-11
+
+    def __add__(self, o): return self._bin("add", self, o)
+    def __radd__(self, o): return self._bin("add", o, self)
+    def __sub__(self, o): return self._bin("sub", self, o)
+    def __rsub__(self, o): return self._bin("sub", o, self)
+    def __mul__(self, o): return self._bin("mul", self, o)
+    def __rmul__(self, o): return self._bin("mul", o, self)
+    def __truediv__(self, o): return self._bin("div", self, o)
+    def __rtruediv__(self, o): return self._bin("div", o, self)
+
+    def mix(self, other, amount):
+        return mix(self, other, amount)
+
+
+class Material(Node):
+    """SurfaceMaterial node (project/materials.rs:5-35): emissive/diffuse/mirror/refractive, Mix, Binary Add."""
+
+    def __add__(self, other):  # lib.lua:88-90 via expression_mt
+        return Material("binary", operator="add", lhs=self, rhs=other)
+
+    def mix(self, other, amount):
+        return mix(self, other, amount)
+
+
+def mix(lhs, rhs, amount):  # lib.lua:104-118
+    cls = Material if isinstance(lhs, Material) or isinstance(rhs, Material) else Expr
+    return cls("mix", lhs=lhs, rhs=rhs, amount=amount)
+
+
+def fresnel(ior, env_ior=1):  # lib.lua:120-125
+    return Expr("fresnel", ior=ior, env_ior=env_ior)
+
+
+def vector(x=0.0, y=0.0, z=0.0, w=0.0):  # lib.lua:128-150 (keyword form == the table form)
+    return Expr("vector", x=x, y=y, z=z, w=w)
+
+
+def blackbody(temperature):  # lib.lua:152-157
+    return Expr("blackbody", temperature=temperature)
+
+
+def spectrum(format="array", min=None, max=None, points=None, name=None):  # lib.lua:159-164; spectra.rs:13-24
+    return Expr("spectrum", format=format, min=min, max=max, points=points, name=name)
+
+
+def rgb(red=0.0, green=0.0, blue=0.0):  # lib.lua:166-176
+    return Expr("rgb", red=red, green=green, blue=blue)
+
+
+def texture(path, *modifiers):  # lib.lua:178-195 -- accepted by the surface, rejected by the compiler (out of scope)
+    props = {"path": path, "linear": "linear" in modifiers, "mono": "mono" in modifiers}
+    return Expr("mono_texture" if props["mono"] else "color_texture", **props)
+
+
+light_source = SimpleNamespace(  # lib.lua:254-258
+    d65=spectrum(name="d65"),
+    a=spectrum(name="a"),
+)
+
+material = SimpleNamespace(  # lib.lua:231-252
+    diffuse=lambda color: Material("diffuse", color=color),
+    emissive=lambda color: Material("emissive", color=color),
+    mirror=lambda color: Material("mirror", color=color),
+    refractive=lambda color, ior, dispersion=None, env_ior=None, env_dispersion=None: Material(
+        "refractive", color=color, ior=ior, dispersion=dispersion, env_ior=env_ior, env_dispersion=env_dispersion
+    ),
+)
+
+shape = SimpleNamespace(  # lib.lua:197-218; WorldObject, project/mod.rs:169-203
+    sphere=lambda position, radius, material, texture_scale=None: Node(
+        "sphere", position=position, radius=radius, material=material, texture_scale=texture_scale
+    ),
+    plane=lambda origin, normal, material, texture_scale=None: Node(
+        "plane", origin=origin, normal=normal, material=material, texture_scale=texture_scale
+    ),
+    mesh=lambda file, materials, scale=None, transform=None: Node("mesh", file=file, materials=materials, scale=scale, transform=transform),
+    ray_marched=lambda **props: Node("ray_marched", **props),
+)
+
+ray_marched = SimpleNamespace(  # lib.lua:220-231 -- accepted, rejected by the compiler (out of scope)
+    quaternion_julia=lambda **props: Node("quaternion_julia", **props),
+    mandelbulb=lambda **props: Node("mandelbulb", **props),
+)
+
+bounds = SimpleNamespace(box=lambda min, max: Node("box", min=min, max=max))  # lib.lua:237-243
+
+light = SimpleNamespace(  # lib.lua:301-307 + WorldObject::DirectionalLight (project/mod.rs:192-196)
+    point=lambda position, color, **ignored: Node("point_light", position=position, color=color),
+    directional=lambda direction, width, color: Node("directional_light", direction=direction, width=width, color=color),
+)
+
+transform = SimpleNamespace(  # lib.lua:260-266; Transform::LookAt, project/mod.rs:243-266
+    look_at=lambda from_=None, to=None, up=None, **kw: Node("look_at", from_=kw.get("from", from_), to=to, up=up),
+)
+
+camera = SimpleNamespace(  # lib.lua:268-274; Camera::Perspective, project/mod.rs:120-129
+    perspective=lambda transform, fov, focus_distance=None, aperture=None: Node(
+        "perspective", transform=transform, fov=fov, focus_distance=focus_distance, aperture=aperture
+    ),
+)
+
+
+def _renderer(type_):
+    def make(pixel_samples, threads=None, bounces=None, light_samples=None, spectrum_samples=None, spectrum_resolution=None,
+             tile_size=None, **extra):
+        # RendererShared, project/mod.rs:152-161. Unknown keys (the scenes' `spectrum_bins`) are ignored like typed_nodes does.
+        return Node(type_, pixel_samples=pixel_samples, threads=threads, bounces=bounces, light_samples=light_samples,
+                    spectrum_samples=spectrum_samples, spectrum_resolution=spectrum_resolution, tile_size=tile_size, extra=extra)
+    return make
+
+
+renderer = SimpleNamespace(  # lib.lua:276-299
+    simple=_renderer("simple"),
+    bidirectional=_renderer("bidirectional"),
+    photon_mapping=_renderer("photon_mapping"),
+)

@@ -1,0 +1,228 @@
+"""The BASELINE.json configurations as project trees.
+
+  C1  Cornell-shaped box made of spheres only, 256x256, 64 spp           (reference CPU-runnable case)
+  C2  test/cornell/box.obj (36 triangles, `light` = emissive quad), 1024x1024, 256 spp
+  C3  C2 scaled x10 without the two blocks + a 819,200-triangle torus-knot "dragon stand-in", 1920x1080, 1024 spp
+  C4  = C3 across 2/4/8 GPUs
+  C5  C3 with the mesh made of dispersive glass (test/dragon/dragon.lua:30-35), bounces 20, 4096 spp
+
+Materials, spectra and camera follow pyrite/test/cornell/cornell.lua:4-35 (spectra re-encoded in data/cornell_spectra.json).
+`dragon.obj` is absent from the reference mount (.MISSING_LARGE_BLOBS); if a file named dragon.obj sits next to this
+module it is used in place of the torus knot."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from .compiler import DATA_DIR, load_obj
+from .project import camera, material, renderer, shape, spectrum, transform, vector
+
+f32 = np.float32
+
+
+def cornell_spectra():
+    with open(os.path.join(DATA_DIR, "cornell_spectra.json")) as f:
+        raw = json.load(f)
+    return {k: spectrum(format="array", min=v["min"], max=v["max"], points=v["points"]) for k, v in raw.items()}
+
+
+def cornell_materials():
+    s = cornell_spectra()
+    return {
+        "light": {"surface": material.emissive(color=s["lamp"] * 3) + material.diffuse(color=0.78)},  # cornell.lua:4-7
+        "white": {"surface": material.diffuse(color=s["white"])},
+        "green": {"surface": material.diffuse(color=s["green"])},
+        "red": {"surface": material.diffuse(color=s["red"])},
+    }
+
+
+def cornell_camera(scale=1.0):
+    return camera.perspective(  # cornell.lua:28-35
+        fov=37.7,
+        transform=transform.look_at(**{"from": vector(-2.78 * scale, -8 * scale, 2.73 * scale), "to": vector(-2.78 * scale, 0, 2.73 * scale),
+                                       "up": vector(z=1)}),
+    )
+
+
+def _simple(pixel_samples, **kw):
+    return renderer.simple(pixel_samples=pixel_samples, **kw)
+
+
+def c1_spheres(width=256, height=256, pixel_samples=64):
+    m = cornell_materials()
+    R = 100.0
+    x0, x1, y1, z0, z1 = -5.56, 0.0, 5.592, 0.0, 5.488
+    cx, cy, cz = (x0 + x1) / 2, y1 / 2, (z0 + z1) / 2
+    objects = [
+        shape.sphere(position=vector(x0 - R, cy, cz), radius=R, material=m["red"]),     # left wall
+        shape.sphere(position=vector(x1 + R, cy, cz), radius=R, material=m["green"]),   # right wall
+        shape.sphere(position=vector(cx, y1 + R, cz), radius=R, material=m["white"]),   # back wall
+        shape.sphere(position=vector(cx, cy, z0 - R), radius=R, material=m["white"]),   # floor
+        shape.sphere(position=vector(cx, cy, z1 + R), radius=R, material=m["white"]),   # ceiling
+        shape.sphere(position=vector(-3.7, 3.3, 0.9), radius=0.9, material=m["white"]),
+        shape.sphere(position=vector(-1.6, 1.7, 0.8), radius=0.8, material=m["white"]),
+        # The lamp sphere is purely emissive (like test/spheres/spheres.lua:29-36). With cornell.lua's `emissive + diffuse`
+        # light material a diffuse hit ON a spherical lamp samples that lamp from its own surface, where
+        # solid_angle_towards returns None (shapes/mod.rs:253-271) and lamp.rs:63-66 falls back to area / distance^2 with
+        # distance ~ 0: unbounded weights (fireflies of 1e12+) that are a reference quirk, not a useful parity workload.
+        shape.sphere(position=vector(-2.78, 2.795, 4.9), radius=0.5, material={"surface": material.emissive(color=cornell_spectra()["lamp"] * 3)}),
+    ]
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": _simple(pixel_samples),
+        "camera": cornell_camera(),
+        "world": {"objects": objects},
+    }
+
+
+def _box_mesh(drop=()):
+    mesh = load_obj(os.path.join(DATA_DIR, "cornell_box.obj"))
+    mesh["objects"] = [o for o in mesh["objects"] if o["name"] not in drop]
+    return mesh
+
+
+def _box_materials(m, names):
+    table = {"light": m["light"], "left": m["red"], "right": m["green"], "tall": m["white"], "short": m["white"], "back": m["white"],
+             "ceiling": m["white"], "floor": m["white"]}  # cornell.lua:41-51
+    return {k: table[k] for k in names}
+
+
+def c2_cornell(width=1024, height=1024, pixel_samples=256):
+    m = cornell_materials()
+    mesh = _box_mesh()
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": _simple(pixel_samples),
+        "camera": cornell_camera(),
+        "world": {"objects": [shape.mesh(file=mesh, materials=_box_materials(m, [o["name"] for o in mesh["objects"]]))]},
+    }
+
+
+def torus_knot_mesh(segments=640, sides=640, p=2, q=3, tube=0.42, noise_seed=7, noise_amp=0.15,
+                    fit_min=(-44.0, 12.0, 0.5), fit_max=(-12.0, 44.0, 32.0)):
+    """(p,q) torus-knot tube, `segments` x `sides` x 2 triangles, radius modulated by seeded value noise, smooth
+    vertex normals, scaled uniformly and translated to fit the given box. Returns (positions [n,3,3], normals [n,3,3])."""
+    t = np.arange(segments, dtype=np.float64) * (2 * np.pi / segments)
+
+    def curve(t):
+        r = 2.0 + np.cos(q * t)
+        return np.stack([r * np.cos(p * t), r * np.sin(p * t), np.sin(q * t)], axis=-1)
+
+    c = curve(t)
+    h = 1e-4
+    tangent = curve(t + h) - curve(t - h)
+    tangent /= np.linalg.norm(tangent, axis=1, keepdims=True)
+    # frame from the direction towards the torus axis: smooth and closed for a torus knot
+    radial = np.stack([np.cos(p * t), np.sin(p * t), np.zeros_like(t)], axis=-1)
+    n1 = radial - (radial * tangent).sum(1, keepdims=True) * tangent
+    n1 /= np.linalg.norm(n1, axis=1, keepdims=True)
+    n2 = np.cross(tangent, n1)
+
+    rng = np.random.RandomState(noise_seed)
+    grid = 16
+    lattice = rng.rand(grid, grid)
+    a = np.arange(segments) * grid / segments
+    b = np.arange(sides) * grid / sides
+    a0, b0 = a.astype(int) % grid, b.astype(int) % grid
+    fa, fb = (a - np.floor(a))[:, None], (b - np.floor(b))[None, :]
+    fa, fb = fa * fa * (3 - 2 * fa), fb * fb * (3 - 2 * fb)
+    v00 = lattice[a0][:, b0]
+    v10 = lattice[(a0 + 1) % grid][:, b0]
+    v01 = lattice[a0][:, (b0 + 1) % grid]
+    v11 = lattice[(a0 + 1) % grid][:, (b0 + 1) % grid]
+    noise = (v00 * (1 - fa) + v10 * fa) * (1 - fb) + (v01 * (1 - fa) + v11 * fa) * fb
+    radius = tube * (1.0 + noise_amp * (2.0 * noise - 1.0))
+
+    phi = np.arange(sides, dtype=np.float64) * (2 * np.pi / sides)
+    ring = np.cos(phi)[None, :, None] * n1[:, None, :] + np.sin(phi)[None, :, None] * n2[:, None, :]
+    verts = c[:, None, :] + radius[:, :, None] * ring  # [segments, sides, 3]
+
+    lo, hi = verts.reshape(-1, 3).min(0), verts.reshape(-1, 3).max(0)
+    fit_min, fit_max = np.asarray(fit_min, dtype=np.float64), np.asarray(fit_max, dtype=np.float64)
+    scale = ((fit_max - fit_min) / (hi - lo)).min()
+    verts = (verts - (lo + hi) / 2) * scale + (fit_min + fit_max) / 2
+    verts = verts.astype(f32)
+
+    i = np.arange(segments)[:, None]
+    j = np.arange(sides)[None, :]
+    i1, j1 = (i + 1) % segments, (j + 1) % sides
+    idx = lambda ii, jj: (ii * sides + jj)  # noqa: E731
+    quad = np.stack([idx(i, j) + 0 * j, idx(i1, j) + 0 * j, idx(i1, j1), idx(i, j1) + 0 * i], axis=-1).reshape(-1, 4)
+    faces = np.concatenate([quad[:, [0, 1, 2]], quad[:, [0, 2, 3]]], axis=0)
+    flat = verts.reshape(-1, 3)
+    tri = flat[faces]  # [n,3,3]
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+    vn = np.zeros((len(flat), 3), dtype=np.float64)
+    for k in range(3):
+        np.add.at(vn, faces[:, k], fn)
+    vn /= np.linalg.norm(vn, axis=1, keepdims=True)
+    normals = vn.astype(f32)[faces]
+    return np.ascontiguousarray(tri, dtype=f32), np.ascontiguousarray(normals, dtype=f32)
+
+
+def _mesh_dict_from_arrays(name, positions, normals):
+    n = len(positions)
+    ar = np.arange(3 * n).reshape(n, 3)
+    polys = [[(int(a), None, int(a)), (int(b), None, int(b)), (int(c), None, int(c))] for a, b, c in ar]
+    return {"position": positions.reshape(-1, 3), "texture": np.zeros((0, 2), dtype=f32), "normal": normals.reshape(-1, 3),
+            "objects": [{"name": name, "polys": polys}]}
+
+
+def c3_mesh_in_box(width=1920, height=1080, pixel_samples=1024, segments=640, sides=640, glass=False, bounces=None):
+    """C3 (and C5 with glass=True). Built through FlatScene's bulk triangle path: see `c3_flat`."""
+    return {"image": {"width": width, "height": height}, "renderer": _simple(pixel_samples, bounces=bounces),
+            "camera": cornell_camera(scale=10.0), "world": None,
+            "flat": lambda: c3_flat(segments=segments, sides=sides, glass=glass)}
+
+
+def c3_flat(segments=640, sides=640, glass=False):
+    from .compiler import FlatScene  # local import: scenes are plain data otherwise
+
+    m = cornell_materials()
+    box = _box_mesh(drop=("tall", "short"))
+    flat = FlatScene()
+    flat.add_world({"objects": [shape.mesh(file=box, scale=10.0, materials=_box_materials(m, [o["name"] for o in box["objects"]]))]})
+    dragon = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dragon.obj")
+    if glass:
+        mesh_material = {"surface": material.refractive(ior=1.5, dispersion=0.01371, color=1)}  # dragon.lua:30-35
+    else:
+        mesh_material = {"surface": material.diffuse(color=0.8)}
+    mat, _ = flat.add_material(mesh_material)
+    if os.path.exists(dragon):
+        mesh = load_obj(dragon)
+        pos, nrm = [], []
+        for o in mesh["objects"]:
+            for poly in o["polys"]:
+                if len(poly) == 3 and all(ix[2] is not None for ix in poly):
+                    pos.append([mesh["position"][ix[0]] for ix in poly])
+                    nrm.append([mesh["normal"][ix[2]] for ix in poly])
+        positions, normals = np.asarray(pos, dtype=f32), np.asarray(nrm, dtype=f32)
+    else:
+        positions, normals = torus_knot_mesh(segments=segments, sides=sides)
+    flat.add_triangles(positions, normals, mat)
+    return flat
+
+
+def build(project, seed=1):
+    """Project tree -> (World, Camera, Renderer, Film) through the same from_project constructors the reference uses
+    (main.rs:111-134 parse_project, :190-195 Film::new)."""
+    from .renderer import Camera, Renderer, World
+
+    r = Renderer.from_project(project["renderer"], seed=seed)
+    cam = Camera.from_project(project["camera"])
+    if project.get("world") is None and "flat" in project:
+        world = World(project["flat"]())
+    else:
+        world = World.from_project(project["world"])
+    film = r.new_film(project["image"]["width"], project["image"]["height"])
+    return world, cam, r, film
+
+
+CONFIGS = {
+    "C1": c1_spheres,
+    "C2": c2_cornell,
+    "C3": c3_mesh_in_box,
+    "C5": lambda **kw: c3_mesh_in_box(glass=True, bounces=20, **{"pixel_samples": 4096, **kw}),
+}

@@ -1,0 +1,139 @@
+"""ctypes wrapper around oracle/liboracle.so -- the CPU restatement of the reference used as the parity checker.
+Test infrastructure only (see oracle/oracle.h): nothing under pyrite_amd/ imports this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pyrite_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+_lib = None
+
+U4 = C.c_uint32 * 4
+F3 = C.c_float * 3
+F6 = C.c_float * 6
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ORACLE_DIR, "oracle.cpp")
+        if not os.path.exists(LIB) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB)):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        L = C.CDLL(LIB)
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_scene_create.argtypes = [C.POINTER(abi.PyrSceneDesc), C.POINTER(C.c_void_p)]
+        L.oracle_scene_destroy.argtypes = [C.c_void_p]
+        L.oracle_render_simple.argtypes = [C.c_void_p, C.POINTER(abi.PyrCamera), C.POINTER(abi.PyrFilmDesc), C.POINTER(abi.PyrRenderParams),
+                                           C.c_void_p, C.c_int, C.POINTER(abi.PyrCounters)]
+        L.oracle_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(abi.PyrCounters)]
+        L.oracle_bvh_num_nodes.argtypes = [C.c_void_p]
+        L.oracle_bvh_num_nodes.restype = C.c_uint32
+        L.oracle_bvh_node.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_rng_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, U4]
+        L.oracle_rng_next_u32.argtypes = [U4]
+        L.oracle_rng_next_u32.restype = C.c_uint32
+        L.oracle_rng_gen_f32.argtypes = [U4]
+        L.oracle_rng_gen_f32.restype = C.c_float
+        L.oracle_rng_gen_range_f32.argtypes = [U4, C.c_float, C.c_float]
+        L.oracle_rng_gen_range_f32.restype = C.c_float
+        L.oracle_rng_gen_range_usize.argtypes = [U4, C.c_uint32]
+        L.oracle_rng_gen_range_usize.restype = C.c_uint32
+        L.oracle_rng_choose_index.argtypes = [U4, C.c_uint32]
+        L.oracle_rng_choose_index.restype = C.c_uint32
+        L.oracle_aabb_intersection_distance.argtypes = [F6, F6, C.POINTER(C.c_float)]
+        L.oracle_schlick.argtypes = [C.c_float, C.c_float, F3, F3]
+        L.oracle_schlick.restype = C.c_float
+        L.oracle_fresnel.argtypes = [C.c_float, C.c_float, F3, F3]
+        L.oracle_fresnel.restype = C.c_float
+        L.oracle_ortho.argtypes = [F3, F3]
+        L.oracle_sample_sphere.argtypes = [U4, F3]
+        L.oracle_sample_hemisphere.argtypes = [U4, F3, F3]
+        L.oracle_sample_cone.argtypes = [U4, F3, C.c_float, F3]
+        L.oracle_solid_angle.argtypes = [C.c_float]
+        L.oracle_solid_angle.restype = C.c_float
+        L.oracle_blackbody.argtypes = [C.c_float, C.c_float]
+        L.oracle_blackbody.restype = C.c_float
+        L.oracle_triangle_intersect.argtypes = [F3, F3, F3, F6, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.oracle_sphere_intersect.argtypes = [F3, C.c_float, F6, C.POINTER(C.c_float), F3]
+        L.oracle_spectrum_get.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint32, C.c_float]
+        L.oracle_spectrum_get.restype = C.c_float
+        L.oracle_refract.argtypes = [U4, C.c_float, C.c_float, F3, F3, F3]
+        L.oracle_refract.restype = C.c_float
+        L.oracle_sample_wavelengths.argtypes = [U4, C.c_float, C.c_float, C.c_uint32, C.c_void_p]
+        L.oracle_wavelength_to_grain.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32]
+        L.oracle_wavelength_to_grain.restype = C.c_uint32
+        L.oracle_to_pixel.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_to_view_area.argtypes = [C.c_uint32] * 6 + [C.c_float * 4]
+        L.oracle_ray_towards.argtypes = [C.POINTER(abi.PyrCamera), U4, C.c_float, C.c_float, F6]
+        L.oracle_tile_order.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.oracle_tile_order.restype = C.c_uint32
+        L.oracle_run_program.argtypes = [C.c_void_p, C.c_uint32, C.c_float, F3, F3, C.c_float * 2, C.POINTER(C.c_int)]
+        L.oracle_run_program.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(status):
+    if status != 0:
+        raise OracleError("oracle error %d: %s" % (status, lib().oracle_last_error().decode()))
+
+
+class OracleScene:
+    def __init__(self, world):
+        """`world` is a pyrite_amd.renderer.World (only its flattened description is used)."""
+        self.world = world
+        self.handle = C.c_void_p()
+        _check(lib().oracle_scene_create(C.byref(world.desc), C.byref(self.handle)))
+
+    def render(self, renderer, camera, film, threads=1, tile_range=None, film_rows=None):
+        params = renderer.params(0, tile_range, film_rows)
+        desc = film.desc()
+        counters = abi.PyrCounters()
+        grains = np.ascontiguousarray(film.grains)
+        _check(lib().oracle_render_simple(self.handle, C.byref(camera.c), C.byref(desc), C.byref(params), grains.ctypes.data, threads,
+                                          C.byref(counters)))
+        if grains is not film.grains:
+            film.grains[...] = grains
+        return counters.as_dict()
+
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        hits = np.zeros(len(rays), dtype=np.dtype([("distance", "<f4"), ("shape", "<u4"), ("u", "<f4"), ("v", "<f4")]))
+        counters = abi.PyrCounters()
+        _check(lib().oracle_intersect(self.handle, rays.ctypes.data, len(rays), hits.ctypes.data, C.byref(counters)))
+        return hits, counters.as_dict()
+
+    def bvh_nodes(self):
+        n = lib().oracle_bvh_num_nodes(self.handle)
+        out = []
+        for i in range(n):
+            aabb = (C.c_float * 6)()
+            size, item = C.c_uint32(), C.c_uint32()
+            _check(lib().oracle_bvh_node(self.handle, i, aabb, C.byref(size), C.byref(item)))
+            out.append((np.array(aabb[:], dtype=np.float32), size.value, item.value))
+        return out
+
+    def run_program(self, program, wavelength, normal=(0, 0, 1), incident=(0, 0, -1), texture=(0, 0)):
+        used = C.c_int(0)
+        v = lib().oracle_run_program(self.handle, program, wavelength, F3(*normal), F3(*incident), (C.c_float * 2)(*texture), C.byref(used))
+        return float(v), bool(used.value)
+
+    def close(self):
+        if self.handle:
+            lib().oracle_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
