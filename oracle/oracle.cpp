@@ -33,6 +33,16 @@ constexpr float DIST_EPSILON = 0.0001f; // math.rs:4
 constexpr float PI = 3.14159265358979323846f; // std::f32::consts::PI
 constexpr float INF = std::numeric_limits<float>::infinity();
 
+// Transcendentals. Rust's f32::sin / cos / acos / exp / atan2 call the platform libm (sinf, ...), whose results are
+// within an ulp of, but not always equal to, the correctly rounded value and differ between libms. The oracle and
+// the HIP kernels both evaluate them through f64 and round once -- the correctly rounded f32 result up to the
+// (about 1e-8 per call) double-rounding cases -- so that the two sides agree bit for bit (DESIGN.md "Arithmetic").
+inline float sin32(float x) { return (float)std::sin((double)x); }
+inline float cos32(float x) { return (float)std::cos((double)x); }
+inline float acos32(float x) { return (float)std::acos((double)x); }
+inline float exp32(float x) { return (float)std::exp((double)x); }
+inline float atan2_32(float y, float x) { return (float)std::atan2((double)y, (double)x); }
+
 // Rust f32::min / f32::max: IEEE minNum / maxNum (a NaN operand is ignored).
 inline float rmin(float a, float b) { return std::fmin(a, b); }
 inline float rmax(float a, float b) { return std::fmax(a, b); }
@@ -236,7 +246,7 @@ inline V3 sample_cone(Rng& rng, V3 direction, float cos_half) {
     float r1 = PI * 2.0f * gen_f32(rng);
     float r2 = cos_half + (1.0f - cos_half) * gen_f32(rng);
     float oneminus = std::sqrt(1.0f - r2 * r2);
-    return o1 * std::cos(r1) * oneminus + o2 * std::sin(r1) * oneminus + direction * r2;
+    return o1 * cos32(r1) * oneminus + o2 * sin32(r1) * oneminus + direction * r2;
 }
 
 // math.rs:139-145 solid_angle.
@@ -250,8 +260,8 @@ inline V3 sample_sphere(Rng& rng) {
     float u = gen_f32(rng);
     float v = gen_f32(rng);
     float theta = 2.0f * PI * u;
-    float phi = std::acos(2.0f * v - 1.0f);
-    return v3(std::sin(phi) * std::cos(theta), std::sin(phi) * std::sin(theta), std::cos(phi));
+    float phi = acos32(2.0f * v - 1.0f);
+    return v3(sin32(phi) * cos32(theta), sin32(phi) * sin32(theta), cos32(phi));
 }
 
 // math.rs:155-164 sample_hemisphere.
@@ -270,7 +280,7 @@ inline float blackbody(float wavelength, float temperature) {
     float a4 = a2 * a2;
     float powi = 1.0f / (wl * a4);
     float power_term = 3.74183e-16f * powi;
-    return power_term / (std::exp(1.4388e-2f / (wl * temperature)) - 1.0f);
+    return power_term / (exp32(1.4388e-2f / (wl * temperature)) - 1.0f);
 }
 
 // math.rs:22-72 Interpolated::get over (x,y) pairs.
@@ -474,8 +484,8 @@ inline SurfaceData surface_data(const OracleScene& s, const Intersection& hit) {
     if (hit.shape.kind == PYR_SHAPE_SPHERE) {
         const Sphere& sp = s.spheres[hit.shape.index];
         V3 normal = normalize(hit.position - sp.position);
-        float latitude = std::acos(normal.y);
-        float longitude = std::atan2(normal.x, normal.z);
+        float latitude = acos32(normal.y);
+        float longitude = atan2_32(normal.x, normal.z);
         sd.normal = normal;
         sd.texture[0] = (longitude * (1.0f / PI) * 0.5f) / sp.tex_scale[0];
         sd.texture[1] = (1.0f - (latitude * (1.0f / PI))) / sp.tex_scale[1];
@@ -1418,8 +1428,8 @@ inline Ray ray_towards(const PyrCamera& cam, float tx, float ty, Rng& rng) {
     if (cam.aperture > 0.0f) {
         float sqrt_r = std::sqrt(cam.aperture * gen_f32(rng));
         float psi = PI * 2.0f * gen_f32(rng);
-        float lens_x = sqrt_r * std::cos(psi);
-        float lens_y = sqrt_r * std::sin(psi);
+        float lens_x = sqrt_r * cos32(psi);
+        float lens_y = sqrt_r * sin32(psi);
         origin = v3(lens_x, lens_y, 0.0f);
         direction = target - origin;
     } else {

@@ -7,7 +7,8 @@ import os
 
 from . import abi
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpyrite_gpu.so")
+# PYRITE_GPU_LIB selects another build of the same library (A/B experiments on kernel variants); never a CPU path.
+LIB_PATH = os.environ.get("PYRITE_GPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpyrite_gpu.so")
 _lib = None
 
 

@@ -1,0 +1,43 @@
+"""In-tree build of csrc/libpyrite_gpu.so (HIP kernels + C-ABI host code) for gfx950.
+
+    python -m pyrite_amd.build [--force]
+
+hipcc cross-compiles without a GPU. The .so stays in-tree (git-ignored, shipped to the GPU box by gpurun)."""
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+OUT = os.path.join(CSRC, "libpyrite_gpu.so")
+SOURCES = ["kernels.hip", "api.cpp", "bvh.cpp"]
+HEADERS = ["bvh.h", "device_scene.h", os.path.join("..", "..", "include", "pyrite_gpu.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    "-munsafe-fp-atomics",  # atomicAdd(float*) -> one global_atomic_add_f32, no CAS loop
+    "-fno-fast-math",
+    "-ffp-contract=off",  # the reference is Rust (never fuses a*b+c); the kernels must round like the CPU oracle does
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, extra_flags=(), verbose=False):
+    if not force and not stale():
+        return OUT
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(OUT)

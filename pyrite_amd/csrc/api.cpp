@@ -1,0 +1,568 @@
+// api.cpp -- host side of the C ABI declared in include/pyrite_gpu.h: scene validation and packing, BVH build,
+// upload, launch orchestration. No radiance is ever computed on the host; without a gfx950 device every render /
+// intersect entry point fails with PYR_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "bvh.h"
+#include "device_scene.h"
+
+using namespace pyr;
+
+namespace {
+
+thread_local std::string g_error;
+int fail(int code, const std::string& message) {
+    g_error = message;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) { return fail(PYR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); }
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() {
+        if (ptr) (void)hipFree(ptr);
+    }
+    int upload(const void* src, size_t n) {
+        bytes = n;
+        if (n == 0) n = 16; // keep pointers non-null
+        HIP_TRY(hipMalloc(&ptr, n));
+        if (bytes) HIP_TRY(hipMemcpy(ptr, src, bytes, hipMemcpyHostToDevice));
+        return PYR_OK;
+    }
+    int alloc(size_t n) {
+        bytes = n;
+        HIP_TRY(hipMalloc(&ptr, n ? n : 16));
+        return PYR_OK;
+    }
+};
+
+int validate(const PyrSceneDesc* d) {
+    if (!d) return fail(PYR_ERR_INVALID_ARGUMENT, "null scene description");
+    if (d->num_programs == 0 || d->sky_program >= d->num_programs) return fail(PYR_ERR_INVALID_ARGUMENT, "sky program out of range");
+    if ((d->num_triangles && (!d->tri_positions || !d->tri_normals || !d->tri_material)) || (d->num_spheres && (!d->spheres || !d->sphere_material)) ||
+        (d->num_planes && (!d->planes || !d->plane_material)))
+        return fail(PYR_ERR_INVALID_ARGUMENT, "null geometry array");
+    if (d->num_triangles >= (1u << 28) || d->num_spheres >= (1u << 28)) return fail(PYR_ERR_INVALID_ARGUMENT, "too many primitives");
+    for (uint32_t i = 0; i < d->num_instrs; ++i) {
+        const PyrInstr& ins = d->instrs[i];
+        if (ins.op == PYR_OP_COLOR_TEXTURE || ins.op == PYR_OP_MONO_TEXTURE) return fail(PYR_ERR_UNSUPPORTED, "texture opcodes are out of scope");
+        if (ins.op > PYR_OP_CLAMP) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown opcode");
+        if (ins.op == PYR_OP_SPECTRUM && ins.a >= d->num_spectra) return fail(PYR_ERR_INVALID_ARGUMENT, "spectrum id out of range");
+        if (ins.op == PYR_OP_RGB_SPECTRUM && !d->rgb_basis) return fail(PYR_ERR_INVALID_ARGUMENT, "RgbSpectrumValue needs rgb_basis");
+    }
+    for (uint32_t i = 0; i < d->num_spectra; ++i) {
+        const PyrSpectrum& s = d->spectra[i];
+        uint64_t floats = s.format == PYR_SPECTRUM_CURVE ? 2ull * s.count : s.count;
+        if (s.offset + floats > d->num_spectrum_floats) return fail(PYR_ERR_INVALID_ARGUMENT, "spectrum data out of range");
+    }
+    for (uint32_t i = 0; i < d->num_programs; ++i) {
+        const PyrProgram& p = d->programs[i];
+        if (p.kind == PYR_PROGRAM_INSTRUCTIONS) {
+            if ((uint64_t)p.first_instr + p.num_instrs > d->num_instrs) return fail(PYR_ERR_INVALID_ARGUMENT, "program instruction range out of bounds");
+            if (p.num_numbers > PYR_MAX_NUMBER_REGISTERS || p.num_vectors > PYR_MAX_VECTOR_REGISTERS || p.num_rgbs > PYR_MAX_RGB_REGISTERS)
+                return fail(PYR_ERR_UNSUPPORTED, "program needs more registers than the GPU VM provides");
+        }
+    }
+    for (uint32_t i = 0; i < d->num_materials; ++i) {
+        const PyrMaterial& m = d->materials[i];
+        if (m.normal_map_program >= 0) return fail(PYR_ERR_UNSUPPORTED, "normal maps are out of scope");
+        if (m.num_components == 0) return fail(PYR_ERR_INVALID_ARGUMENT, "material without components");
+        if ((uint64_t)m.first_component + m.num_components > d->num_components || (uint64_t)m.first_emissive + m.num_emissive > d->num_components)
+            return fail(PYR_ERR_INVALID_ARGUMENT, "material component range out of bounds");
+    }
+    for (uint32_t i = 0; i < d->num_components; ++i) {
+        const PyrComponent& c = d->components[i];
+        if (c.bsdf > PYR_BSDF_REFRACTIVE) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown bsdf");
+        if (c.color_program >= d->num_programs || (c.probability_program >= 0 && (uint32_t)c.probability_program >= d->num_programs))
+            return fail(PYR_ERR_INVALID_ARGUMENT, "component program out of range");
+    }
+    for (uint32_t i = 0; i < d->num_triangles; ++i)
+        if (d->tri_material[i] >= d->num_materials) return fail(PYR_ERR_INVALID_ARGUMENT, "triangle material out of range");
+    for (uint32_t i = 0; i < d->num_spheres; ++i)
+        if (d->sphere_material[i] >= d->num_materials) return fail(PYR_ERR_INVALID_ARGUMENT, "sphere material out of range");
+    for (uint32_t i = 0; i < d->num_planes; ++i)
+        if (d->plane_material[i] >= d->num_materials) return fail(PYR_ERR_INVALID_ARGUMENT, "plane material out of range");
+    for (uint32_t i = 0; i < d->num_lamps; ++i) {
+        const PyrLamp& l = d->lamps[i];
+        if (l.kind == PYR_LAMP_SHAPE) {
+            uint32_t limit = l.shape_kind == PYR_SHAPE_SPHERE ? d->num_spheres : (l.shape_kind == PYR_SHAPE_TRIANGLE ? d->num_triangles : 0);
+            if (l.shape_index >= limit) return fail(PYR_ERR_INVALID_ARGUMENT, "lamp shape out of range");
+            uint32_t mat = l.shape_kind == PYR_SHAPE_SPHERE ? d->sphere_material[l.shape_index] : d->tri_material[l.shape_index];
+            if (d->materials[mat].num_emissive == 0) return fail(PYR_ERR_INVALID_ARGUMENT, "lamp shape has no emissive component");
+        } else if (l.kind > PYR_LAMP_SHAPE || l.color_program >= d->num_programs) {
+            return fail(PYR_ERR_INVALID_ARGUMENT, "lamp program out of range");
+        }
+    }
+    return PYR_OK;
+}
+
+float bits_to_float(uint32_t b) {
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+float shape_bits(uint32_t shape) { return bits_to_float(shape); }
+
+bool operand_is_wavelength(const PyrOperand& o) { return o.kind == PYR_OPERAND_INPUT && o.bits == PYR_INPUT_WAVELENGTH; }
+
+// Which operand slots an opcode evaluates (execution_context.rs:81-281): decides ProbabilityInput::wavelength_used.
+bool instr_reads_wavelength(const PyrInstr& ins) {
+    switch (ins.op) {
+    case PYR_OP_VECTOR: return operand_is_wavelength(ins.x) || operand_is_wavelength(ins.y) || operand_is_wavelength(ins.z) || operand_is_wavelength(ins.w);
+    case PYR_OP_RGB:
+    case PYR_OP_CLAMP: return operand_is_wavelength(ins.x) || operand_is_wavelength(ins.y) || operand_is_wavelength(ins.z);
+    case PYR_OP_SPECTRUM:
+    case PYR_OP_RGB_SPECTRUM:
+    case PYR_OP_MIX: return operand_is_wavelength(ins.x);
+    case PYR_OP_FRESNEL:
+    case PYR_OP_BLACKBODY: return operand_is_wavelength(ins.x) || operand_is_wavelength(ins.y);
+    default: return false;
+    }
+}
+
+DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
+    DevProgram o{};
+    o.kind = p.kind;
+    o.constant = p.constant;
+    o.first_instr = p.first_instr;
+    o.num_instrs = p.num_instrs;
+    o.output_kind = p.output_kind;
+    o.output_reg = p.output_reg;
+    o.fast = FAST_NONE;
+    if (p.kind != PYR_PROGRAM_INSTRUCTIONS) return o;
+    const PyrInstr* I = d->instrs + p.first_instr;
+    for (uint32_t k = 0; k < p.num_instrs; ++k)
+        if (instr_reads_wavelength(I[k])) o.reads_wavelength = 1;
+    auto is_spectrum = [&](const PyrInstr& ins) { return ins.op == PYR_OP_SPECTRUM && operand_is_wavelength(ins.x); };
+    auto is_mul = [&](const PyrInstr& ins) { return ins.op == PYR_OP_BINARY && ins.value_type == PYR_VT_NUMBER && ins.operator_ == PYR_BIN_MUL; };
+    if (p.output_kind != PYR_OUTPUT_NUMBER) return o;
+    if (p.num_instrs == 1 && is_spectrum(I[0]) && p.output_reg == I[0].output) {
+        o.fast = FAST_SPECTRUM;
+        o.fast_spectrum = I[0].a;
+    } else if (p.num_instrs == 3 && is_mul(I[2]) && p.output_reg == I[2].output) {
+        // [Spectrum -> r, Number c -> q, r * q] or [Number c -> q, Spectrum -> r, q * r] (compiler.rs convert_operands order)
+        if (is_spectrum(I[0]) && I[1].op == PYR_OP_NUMBER && I[2].a == I[0].output && I[2].b == I[1].output && I[0].output != I[1].output) {
+            o.fast = FAST_SPECTRUM_MUL;
+            o.fast_spectrum = I[0].a;
+            o.fast_scale = bits_to_float(I[1].x.bits);
+        } else if (I[0].op == PYR_OP_NUMBER && is_spectrum(I[1]) && I[2].a == I[0].output && I[2].b == I[1].output && I[0].output != I[1].output) {
+            o.fast = FAST_MUL_SPECTRUM;
+            o.fast_spectrum = I[1].a;
+            o.fast_scale = bits_to_float(I[0].x.bits);
+        }
+    }
+    return o;
+}
+
+} // namespace
+
+struct PyrScene {
+    int device = 0;
+    int num_cus = 0;
+    DevScene dev{};
+    PyrBvhInfo info{};
+    DeviceBuffer nodes, prims, tri_shade, spheres, sphere_material, planes, plane_material, lamps, materials, components, programs, instrs, spectra,
+        spectrum_data, rgb_basis, counters;
+    PyrCounters last_counters{};
+    bool have_counters = false;
+};
+
+namespace {
+
+int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
+    // ---- primitives + BVH
+    std::vector<PrimBounds> bounds;
+    bounds.reserve((size_t)d->num_spheres + d->num_triangles);
+    for (uint32_t i = 0; i < d->num_spheres; ++i) { // Bounded::aabb, shapes/mod.rs:411-416
+        const float* p = d->spheres + 4 * (size_t)i;
+        PrimBounds b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = p[a] - p[3];
+            b.hi[a] = p[a] + p[3];
+        }
+        b.shape = ((uint32_t)PYR_SHAPE_SPHERE << 30) | i;
+        bounds.push_back(b);
+    }
+    for (uint32_t i = 0; i < d->num_triangles; ++i) { // shapes/mod.rs:417-428
+        const float* p = d->tri_positions + 9 * (size_t)i;
+        PrimBounds b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = std::min(p[a], std::min(p[3 + a], p[6 + a]));
+            b.hi[a] = std::max(p[a], std::max(p[3 + a], p[6 + a]));
+        }
+        b.shape = ((uint32_t)PYR_SHAPE_TRIANGLE << 30) | i;
+        bounds.push_back(b);
+    }
+    BuiltBvh bvh = build_bvh(bounds);
+    if (bvh.max_depth > 96) return fail(PYR_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack allows");
+
+    std::vector<DevPrim> prims(bvh.prim_order.size());
+    for (size_t k = 0; k < prims.size(); ++k) {
+        uint32_t shape = bvh.prim_order[k], index = shape & 0x3FFFFFFFu;
+        DevPrim& o = prims[k];
+        std::memset(&o, 0, sizeof(o));
+        if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
+            const float* p = d->tri_positions + 9 * (size_t)index;
+            for (int a = 0; a < 3; ++a) {
+                o.a[a] = p[a];
+                o.b[a] = p[3 + a] - p[a]; // edge1 = v2 - v1, edge2 = v3 - v1 (world.rs:330-331, shapes/mod.rs:338-339)
+                o.c[a] = p[6 + a] - p[a];
+            }
+        } else {
+            const float* p = d->spheres + 4 * (size_t)index;
+            for (int a = 0; a < 3; ++a) o.a[a] = p[a];
+            o.b[0] = p[3];
+        }
+        o.a[3] = shape_bits(shape);
+    }
+    std::vector<DevTriShade> shade(d->num_triangles);
+    for (uint32_t i = 0; i < d->num_triangles; ++i) {
+        const float* n = d->tri_normals + 9 * (size_t)i;
+        DevTriShade& o = shade[i];
+        std::memset(&o, 0, sizeof(o));
+        for (int a = 0; a < 3; ++a) {
+            o.n1[a] = n[a];
+            o.n2[a] = n[3 + a];
+            o.n3[a] = n[6 + a];
+        }
+        o.n1[3] = bits_to_float(d->tri_material[i]);
+    }
+    std::vector<DevLamp> lamps(d->num_lamps);
+    for (uint32_t i = 0; i < d->num_lamps; ++i) {
+        const PyrLamp& l = d->lamps[i];
+        DevLamp& o = lamps[i];
+        std::memset(&o, 0, sizeof(o));
+        o.kind = l.kind;
+        o.shape_kind = l.shape_kind;
+        o.shape_index = l.shape_index;
+        o.color_program = l.color_program;
+        for (int a = 0; a < 3; ++a) o.v[a] = l.v[a];
+        o.width = l.width;
+        if (l.kind == PYR_LAMP_SHAPE && l.shape_kind == PYR_SHAPE_SPHERE) {
+            const float* p = d->spheres + 4 * (size_t)l.shape_index;
+            for (int a = 0; a < 3; ++a) o.v[a] = p[a];
+            o.width = p[3];
+            o.area = p[3] * p[3] * 4.0f * 3.14159265358979323846f; // Shape::surface_area, shapes/mod.rs:275
+            o.material = d->sphere_material[l.shape_index];
+        } else if (l.kind == PYR_LAMP_SHAPE) {
+            const float* p = d->tri_positions + 9 * (size_t)l.shape_index;
+            const float* n = d->tri_normals + 9 * (size_t)l.shape_index;
+            for (int a = 0; a < 3; ++a) {
+                o.p1[a] = p[a];
+                o.p2[a] = p[3 + a];
+                o.p3[a] = p[6 + a];
+                o.n1[a] = n[a];
+                o.n2[a] = n[3 + a];
+                o.n3[a] = n[6 + a];
+            }
+            // 0.5 * |a x b| (shapes/mod.rs:276-285), evaluated in f32 without fusing
+            volatile float ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2];
+            volatile float bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
+            volatile float m1 = ay * bz, m2 = az * by, m3 = az * bx, m4 = ax * bz, m5 = ax * by, m6 = ay * bx;
+            volatile float cx = m1 - m2, cy = m3 - m4, cz = m5 - m6;
+            volatile float xx = cx * cx, yy = cy * cy, zz = cz * cz;
+            volatile float s1 = xx + yy;
+            volatile float s2 = s1 + zz;
+            o.area = 0.5f * std::sqrt(s2);
+            o.material = d->tri_material[l.shape_index];
+        }
+    }
+    std::vector<DevProgram> programs(d->num_programs);
+    for (uint32_t i = 0; i < d->num_programs; ++i) programs[i] = pack_program(d, d->programs[i]);
+
+    int rc;
+    if ((rc = s->nodes.upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64)))) return rc;
+    if ((rc = s->prims.upload(prims.data(), prims.size() * sizeof(DevPrim)))) return rc;
+    if ((rc = s->tri_shade.upload(shade.data(), shade.size() * sizeof(DevTriShade)))) return rc;
+    if ((rc = s->spheres.upload(d->spheres, (size_t)d->num_spheres * 16))) return rc;
+    if ((rc = s->sphere_material.upload(d->sphere_material, (size_t)d->num_spheres * 4))) return rc;
+    if ((rc = s->planes.upload(d->planes, (size_t)d->num_planes * 32))) return rc;
+    if ((rc = s->plane_material.upload(d->plane_material, (size_t)d->num_planes * 4))) return rc;
+    if ((rc = s->lamps.upload(lamps.data(), lamps.size() * sizeof(DevLamp)))) return rc;
+    if ((rc = s->materials.upload(d->materials, (size_t)d->num_materials * sizeof(PyrMaterial)))) return rc;
+    if ((rc = s->components.upload(d->components, (size_t)d->num_components * sizeof(PyrComponent)))) return rc;
+    if ((rc = s->programs.upload(programs.data(), programs.size() * sizeof(DevProgram)))) return rc;
+    if ((rc = s->instrs.upload(d->instrs, (size_t)d->num_instrs * sizeof(PyrInstr)))) return rc;
+    if ((rc = s->spectra.upload(d->spectra, (size_t)d->num_spectra * sizeof(PyrSpectrum)))) return rc;
+    if ((rc = s->spectrum_data.upload(d->spectrum_data, (size_t)d->num_spectrum_floats * 4))) return rc;
+    if ((rc = s->rgb_basis.upload(d->rgb_basis, d->rgb_basis ? (size_t)d->rgb_basis_count * 12 : 0))) return rc;
+    if ((rc = s->counters.alloc(sizeof(PyrCounters)))) return rc;
+
+    DevScene& v = s->dev;
+    v.nodes = (const float*)s->nodes.ptr;
+    v.prims = (const float*)s->prims.ptr;
+    v.tri_shade = (const float*)s->tri_shade.ptr;
+    v.spheres = (const float*)s->spheres.ptr;
+    v.sphere_material = (const uint32_t*)s->sphere_material.ptr;
+    v.planes = (const float*)s->planes.ptr;
+    v.plane_material = (const uint32_t*)s->plane_material.ptr;
+    v.lamps = (const DevLamp*)s->lamps.ptr;
+    v.materials = (const PyrMaterial*)s->materials.ptr;
+    v.components = (const PyrComponent*)s->components.ptr;
+    v.programs = (const DevProgram*)s->programs.ptr;
+    v.instrs = (const PyrInstr*)s->instrs.ptr;
+    v.spectra = (const PyrSpectrum*)s->spectra.ptr;
+    v.spectrum_data = (const float*)s->spectrum_data.ptr;
+    v.rgb_basis = (const float*)s->rgb_basis.ptr;
+    v.num_planes = d->num_planes;
+    v.num_lamps = d->num_lamps;
+    v.rgb_count = d->rgb_basis ? d->rgb_basis_count : 0;
+    v.rgb_min = d->rgb_basis_min;
+    v.rgb_max = d->rgb_basis_max;
+    v.sky_program = d->sky_program;
+    v.stack_depth = std::max(1u, bvh.max_depth);
+
+    s->info.num_nodes = (uint32_t)bvh.nodes.size();
+    s->info.num_leaves = bvh.num_leaves;
+    s->info.max_depth = bvh.max_depth;
+    s->info.num_primitives = (uint32_t)prims.size();
+    s->info.node_bytes = bvh.nodes.size() * sizeof(Node64);
+    s->info.primitive_bytes = prims.size() * sizeof(DevPrim);
+    return PYR_OK;
+}
+
+struct TilePlan {
+    uint32_t tiles_x = 0, tiles_y = 0;
+    uint32_t chunks_interior = 0, chunks_right = 0, chunks_bottom = 0, chunks_corner = 0;
+    uint32_t chunk_begin = 0, chunk_end = 0; // image-wide chunk numbers of [tile_begin, tile_end)
+};
+
+int plan_tiles(const PyrFilmDesc* film, const PyrRenderParams* p, TilePlan& plan) {
+    // make_tiles, renderer/algorithm.rs:158-166
+    const uint32_t ts = p->tile_size;
+    plan.tiles_x = (film->width + ts - 1) / ts;
+    plan.tiles_y = (film->height + ts - 1) / ts;
+    const uint32_t total = plan.tiles_x * plan.tiles_y;
+    const uint32_t begin = p->tile_begin, end = p->tile_end ? p->tile_end : total;
+    if (begin > end || end > total) return fail(PYR_ERR_INVALID_ARGUMENT, "tile range out of bounds");
+    const uint64_t w_last = film->width - (uint64_t)(plan.tiles_x - 1) * ts, h_last = film->height - (uint64_t)(plan.tiles_y - 1) * ts;
+    auto chunks = [&](uint64_t w, uint64_t h) { return (w * h * p->pixel_samples + 63) / 64; }; // iterations: simple.rs:73
+    const uint64_t c_int = chunks(ts, ts), c_right = chunks(w_last, ts), c_bottom = chunks(ts, h_last), c_corner = chunks(w_last, h_last);
+    auto prefix = [&](uint32_t tile) -> uint64_t { // chunks of all tiles before `tile`
+        const uint64_t row = (uint64_t)(plan.tiles_x - 1) * c_int + c_right;
+        uint32_t ty = tile / plan.tiles_x, tx = tile % plan.tiles_x;
+        if (ty < plan.tiles_y - 1) return ty * row + tx * c_int;
+        if (ty == plan.tiles_y - 1) return (uint64_t)(plan.tiles_y - 1) * row + tx * c_bottom;
+        return (uint64_t)(plan.tiles_y - 1) * row + (uint64_t)(plan.tiles_x - 1) * c_bottom + c_corner; // tile == total
+    };
+    if (prefix(total) >= 0xFFFFFFFFull || c_int >= 0xFFFFFFFFull) return fail(PYR_ERR_UNSUPPORTED, "too many samples for one image: more than 2^32 chunks");
+    plan.chunks_interior = (uint32_t)c_int;
+    plan.chunks_right = (uint32_t)c_right;
+    plan.chunks_bottom = (uint32_t)c_bottom;
+    plan.chunks_corner = (uint32_t)c_corner;
+    plan.chunk_begin = (uint32_t)prefix(begin);
+    plan.chunk_end = (uint32_t)prefix(end);
+    return PYR_OK;
+}
+
+int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* p, const void* film_ptr) {
+    if (!scene || !camera || !film || !p || !film_ptr) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    if (film->width == 0 || film->height == 0 || film->bins == 0 || p->tile_size == 0 || p->spectrum_samples == 0)
+        return fail(PYR_ERR_INVALID_ARGUMENT, "zero-sized parameter");
+    if (!(film->wl_width > 0.0f)) return fail(PYR_ERR_INVALID_ARGUMENT, "empty wavelength span");
+    uint32_t rows = p->film_row_count ? p->film_row_count : film->height;
+    if ((uint64_t)p->film_row_begin + rows > film->height) return fail(PYR_ERR_INVALID_ARGUMENT, "film window exceeds the image");
+    if (p->spectrum_samples > 64) return fail(PYR_ERR_UNSUPPORTED, "spectrum_samples > 64");
+    return PYR_OK;
+}
+
+RenderLaunch make_launch(const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* p, const TilePlan& plan) {
+    RenderLaunch L{};
+    L.camera = *camera;
+    L.film = *film;
+    L.bounces = p->bounces;
+    L.light_samples = p->light_samples;
+    L.spectrum_samples = p->spectrum_samples;
+    L.tile_size = p->tile_size;
+    L.pixel_samples = p->pixel_samples;
+    L.tiles_x = plan.tiles_x;
+    L.tiles_y = plan.tiles_y;
+    L.chunks_interior = plan.chunks_interior;
+    L.chunks_right = plan.chunks_right;
+    L.chunks_bottom = plan.chunks_bottom;
+    L.chunks_corner = plan.chunks_corner;
+    L.chunk_begin = plan.chunk_begin;
+    L.chunk_end = plan.chunk_end;
+    L.film_row_begin = p->film_row_begin;
+    L.film_row_count = p->film_row_count ? p->film_row_count : film->height;
+    L.seed = p->seed;
+    L.grains_per_wavelength = (float)film->bins / film->wl_width; // film.rs:38
+    return L;
+}
+
+} // namespace
+
+extern "C" {
+
+int pyr_abi_version(void) { return PYR_ABI_VERSION; }
+
+int pyr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pyr_last_error(void) { return g_error.c_str(); }
+
+int pyr_scene_create(const PyrSceneDesc* desc, int device, PyrScene** out_scene) {
+    if (!out_scene) return fail(PYR_ERR_INVALID_ARGUMENT, "null out pointer");
+    *out_scene = nullptr;
+    int rc = validate(desc);
+    if (rc != PYR_OK) return rc;
+    int n = pyr_device_count();
+    if (n <= 0) return fail(PYR_ERR_DEVICE, "no HIP device is visible; pyrite_gpu has no CPU path");
+    if (device < 0 || device >= n) return fail(PYR_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    std::unique_ptr<PyrScene> s(new PyrScene());
+    s->device = device;
+    s->num_cus = prop.multiProcessorCount;
+    rc = pack_and_upload(desc, s.get());
+    if (rc != PYR_OK) return rc;
+    *out_scene = s.release();
+    return PYR_OK;
+}
+
+void pyr_scene_destroy(PyrScene* scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int pyr_render_simple_device(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* params,
+                             PyrGrain* film_device, void* hip_stream) {
+    int rc = check_render_args(scene, camera, film, params, film_device);
+    if (rc != PYR_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    TilePlan plan;
+    if ((rc = plan_tiles(film, params, plan)) != PYR_OK) return rc;
+    if (plan.chunk_end == plan.chunk_begin) return PYR_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    RenderLaunch L = make_launch(camera, film, params, plan);
+    L.film_out = film_device;
+    const bool count = (params->flags & PYR_FLAG_COUNTERS) != 0;
+    if (count) {
+        HIP_TRY(hipMemsetAsync(scene->counters.ptr, 0, sizeof(PyrCounters), stream));
+        L.counters = (unsigned long long*)scene->counters.ptr;
+        scene->have_counters = true;
+    }
+    rc = launch_render(scene->dev, L, count, stream, scene->num_cus);
+    if (rc != PYR_OK) return fail(rc, kernels_last_error());
+    return PYR_OK;
+}
+
+int pyr_render_simple(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* params, PyrGrain* film_inout,
+                      PyrProgressFn on_status, void* user) {
+    int rc = check_render_args(scene, camera, film, params, film_inout);
+    if (rc != PYR_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    TilePlan plan;
+    if ((rc = plan_tiles(film, params, plan)) != PYR_OK) return rc;
+    const char* message = "Rendering"; // simple.rs:30
+    if (on_status) on_status(user, 0, message);
+    uint32_t rows = params->film_row_count ? params->film_row_count : film->height;
+    size_t bytes = (size_t)rows * film->width * film->bins * sizeof(PyrGrain);
+    DeviceBuffer film_dev;
+    if ((rc = film_dev.upload(film_inout, bytes)) != PYR_OK) return rc;
+    RenderLaunch L = make_launch(camera, film, params, plan);
+    L.film_out = (PyrGrain*)film_dev.ptr;
+    const bool count = (params->flags & PYR_FLAG_COUNTERS) != 0;
+    if (count) {
+        HIP_TRY(hipMemset(scene->counters.ptr, 0, sizeof(PyrCounters)));
+        L.counters = (unsigned long long*)scene->counters.ptr;
+        scene->have_counters = true;
+    }
+    // With a progress callback the chunk range is cut into slices so the caller hears back between launches
+    // (the reference reports after every finished tile, simple.rs:49-55); results do not depend on the slicing.
+    const uint32_t total_chunks = plan.chunk_end - plan.chunk_begin;
+    const uint32_t slices = on_status ? std::min<uint32_t>(20, std::max<uint32_t>(1, total_chunks / 4096)) : 1;
+    for (uint32_t sidx = 0; sidx < slices; ++sidx) {
+        RenderLaunch part = L;
+        part.chunk_begin = plan.chunk_begin + (uint32_t)((uint64_t)total_chunks * sidx / slices);
+        part.chunk_end = plan.chunk_begin + (uint32_t)((uint64_t)total_chunks * (sidx + 1) / slices);
+        rc = launch_render(scene->dev, part, count, nullptr, scene->num_cus);
+        if (rc != PYR_OK) return fail(rc, kernels_last_error());
+        HIP_TRY(hipDeviceSynchronize());
+        if (on_status) on_status(user, (uint8_t)((sidx + 1) * 100 / slices), message);
+    }
+    HIP_TRY(hipMemcpy(film_inout, film_dev.ptr, bytes, hipMemcpyDeviceToHost));
+    return PYR_OK;
+}
+
+int pyr_scene_counters(PyrScene* scene, PyrCounters* out) {
+    if (!scene || !out) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    if (!scene->have_counters) return fail(PYR_ERR_INVALID_ARGUMENT, "no render with PYR_FLAG_COUNTERS has run on this scene");
+    HIP_TRY(hipSetDevice(scene->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, scene->counters.ptr, sizeof(PyrCounters), hipMemcpyDeviceToHost));
+    return PYR_OK;
+}
+
+int pyr_scene_intersect_device(PyrScene* scene, const float* rays_device, uint32_t n, PyrHit* hits_device, void* hip_stream) {
+    if (!scene || (n && (!rays_device || !hits_device))) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(scene->device));
+    IntersectLaunch L{rays_device, hits_device, n, nullptr};
+    int rc = launch_intersect(scene->dev, L, false, hip_stream);
+    if (rc != PYR_OK) return fail(rc, kernels_last_error());
+    return PYR_OK;
+}
+
+int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* hits, float* elapsed_ms, PyrCounters* counters) {
+    if (!scene || (n && (!rays || !hits))) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(scene->device));
+    if (elapsed_ms) *elapsed_ms = 0.0f;
+    if (counters) std::memset(counters, 0, sizeof(*counters));
+    if (n == 0) return PYR_OK;
+    DeviceBuffer rays_dev, hits_dev;
+    int rc;
+    if ((rc = rays_dev.upload(rays, (size_t)n * 24)) != PYR_OK) return rc;
+    if ((rc = hits_dev.alloc((size_t)n * sizeof(PyrHit))) != PYR_OK) return rc;
+    IntersectLaunch L{(const float*)rays_dev.ptr, (PyrHit*)hits_dev.ptr, n, nullptr};
+    if (counters) {
+        HIP_TRY(hipMemset(scene->counters.ptr, 0, sizeof(PyrCounters)));
+        L.counters = (unsigned long long*)scene->counters.ptr;
+        rc = launch_intersect(scene->dev, L, true, nullptr);
+        if (rc != PYR_OK) return fail(rc, kernels_last_error());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(counters, scene->counters.ptr, sizeof(PyrCounters), hipMemcpyDeviceToHost));
+        L.counters = nullptr;
+    }
+    hipEvent_t start, stop;
+    HIP_TRY(hipEventCreate(&start));
+    HIP_TRY(hipEventCreate(&stop));
+    HIP_TRY(hipEventRecord(start, nullptr));
+    rc = launch_intersect(scene->dev, L, false, nullptr);
+    if (rc != PYR_OK) return fail(rc, kernels_last_error());
+    HIP_TRY(hipEventRecord(stop, nullptr));
+    HIP_TRY(hipEventSynchronize(stop));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, start, stop));
+    (void)hipEventDestroy(start);
+    (void)hipEventDestroy(stop);
+    if (elapsed_ms) *elapsed_ms = ms;
+    HIP_TRY(hipMemcpy(hits, hits_dev.ptr, (size_t)n * sizeof(PyrHit), hipMemcpyDeviceToHost));
+    return PYR_OK;
+}
+
+int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out) {
+    if (!scene || !out) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    *out = scene->info;
+    return PYR_OK;
+}
+
+} // extern "C"

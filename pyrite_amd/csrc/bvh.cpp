@@ -1,0 +1,226 @@
+// bvh.cpp -- binned-SAH builder for the 64-byte two-child node layout (see bvh.h).
+#include "bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace pyr {
+namespace {
+
+constexpr int kBins = 16;
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+struct Box {
+    float lo[3] = {kInf, kInf, kInf};
+    float hi[3] = {-kInf, -kInf, -kInf};
+    void grow(const float* l, const float* h) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], l[a]);
+            hi[a] = std::max(hi[a], h[a]);
+        }
+    }
+    void grow(const Box& b) { grow(b.lo, b.hi); }
+    void grow_point(const float* p) { grow(p, p); }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dx * dz + dy * dz;
+    }
+};
+
+struct Ref {
+    float lo[3], hi[3], c[3];
+    uint32_t shape;
+};
+
+struct Task {
+    uint32_t begin, end, depth;
+    int32_t parent; // node that receives this subtree, -1 for the root
+    int slot;       // which child of `parent`
+};
+
+inline uint32_t ceil_log2(uint32_t n) {
+    uint32_t l = 0;
+    while ((1u << l) < n) ++l;
+    return l;
+}
+
+} // namespace
+
+BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
+    BuiltBvh out;
+    const uint32_t n = (uint32_t)prims.size();
+    std::vector<Ref> refs(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            refs[i].lo[a] = prims[i].lo[a];
+            refs[i].hi[a] = prims[i].hi[a];
+            refs[i].c[a] = 0.5f * prims[i].lo[a] + 0.5f * prims[i].hi[a];
+        }
+        refs[i].shape = prims[i].shape;
+    }
+
+    auto set_child = [&](int32_t parent, int slot, int32_t code, const Box& box) {
+        Node64& p = out.nodes[parent];
+        if (slot == 0) {
+            p.child0 = code;
+            for (int a = 0; a < 3; ++a) {
+                p.lo0[a] = box.lo[a];
+                p.hi0[a] = box.hi[a];
+            }
+        } else {
+            p.child1 = code;
+            for (int a = 0; a < 3; ++a) {
+                p.lo1[a] = box.lo[a];
+                p.hi1[a] = box.hi[a];
+            }
+        }
+    };
+    auto empty_node = []() {
+        Node64 nd{};
+        for (int a = 0; a < 3; ++a) {
+            nd.lo0[a] = nd.lo1[a] = kInf; // an empty child never passes the slab test
+            nd.hi0[a] = nd.hi1[a] = -kInf;
+        }
+        nd.child0 = nd.child1 = encode_leaf(0, 0);
+        return nd;
+    };
+
+    // The root is always a node; a scene with <= kMaxLeafPrims primitives hangs one leaf under it.
+    out.nodes.push_back(empty_node());
+    if (n == 0) return out;
+
+    auto make_leaf = [&](const Task& t, const Box& box) {
+        uint32_t first = (uint32_t)out.prim_order.size();
+        for (uint32_t i = t.begin; i < t.end; ++i) out.prim_order.push_back(refs[i].shape);
+        set_child(t.parent, t.slot, encode_leaf(first, t.end - t.begin), box);
+        out.num_leaves++;
+        out.max_depth = std::max(out.max_depth, t.depth);
+    };
+
+    std::vector<Task> stack;
+    // Root split: children of node 0. Handle it by treating the whole range as a task whose result is written
+    // into a virtual parent; simpler: split the root range here, in the same code path as every other inner node.
+    struct Pending {
+        Task task;
+    };
+    // Task semantics: build the subtree for [begin,end) and store it as child `slot` of `parent`.
+    // Depth counts edges from the root node; children of the root sit at depth 1.
+    auto bounds_of = [&](uint32_t b, uint32_t e, Box& box, Box& cbox) {
+        for (uint32_t i = b; i < e; ++i) {
+            box.grow(refs[i].lo, refs[i].hi);
+            cbox.grow_point(refs[i].c);
+        }
+    };
+
+    // Splits [begin,end) and returns mid; false when the range should become a leaf.
+    auto split = [&](uint32_t begin, uint32_t end, uint32_t depth, const Box& box, const Box& cbox, uint32_t& mid) -> bool {
+        uint32_t count = end - begin;
+        if (count <= 1) return false;
+        // Depth bound: once the remaining budget only just fits a balanced tree, split at the median.
+        bool force_median = depth + ceil_log2((count + kMaxLeafPrims - 1) / kMaxLeafPrims) + 1 >= kMaxBvhDepth;
+        float best_cost = kInf;
+        int best_axis = -1, best_bin = -1;
+        if (!force_median) {
+            for (int a = 0; a < 3; ++a) {
+                float extent = cbox.hi[a] - cbox.lo[a];
+                if (!(extent > 0.0f)) continue;
+                Box bin_box[kBins];
+                uint32_t bin_count[kBins] = {0};
+                float scale = (float)kBins / extent;
+                for (uint32_t i = begin; i < end; ++i) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((refs[i].c[a] - cbox.lo[a]) * scale)));
+                    bin_box[b].grow(refs[i].lo, refs[i].hi);
+                    bin_count[b]++;
+                }
+                float right_area[kBins];
+                uint32_t right_count[kBins];
+                Box acc;
+                uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bin_box[b]);
+                    cnt += bin_count[b];
+                    right_area[b] = acc.half_area();
+                    right_count[b] = cnt;
+                }
+                Box left;
+                uint32_t lcnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    left.grow(bin_box[b]);
+                    lcnt += bin_count[b];
+                    if (lcnt == 0 || right_count[b + 1] == 0) continue;
+                    float cost = left.half_area() * (float)lcnt + right_area[b + 1] * (float)right_count[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = a;
+                        best_bin = b;
+                    }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            // SAH termination: a leaf costs `count` primitive tests, a split costs one node visit plus the children.
+            float parent_area = box.half_area();
+            float split_cost = 1.0f + (parent_area > 0.0f ? best_cost / parent_area : kInf);
+            if (count <= kMaxLeafPrims && (float)count <= split_cost) return false;
+            float extent = cbox.hi[best_axis] - cbox.lo[best_axis];
+            float scale = (float)kBins / extent;
+            float lo = cbox.lo[best_axis];
+            auto it = std::partition(refs.begin() + begin, refs.begin() + end, [&](const Ref& r) {
+                int b = std::min(kBins - 1, std::max(0, (int)((r.c[best_axis] - lo) * scale)));
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - refs.begin());
+            if (mid > begin && mid < end) return true;
+        }
+        if (count <= kMaxLeafPrims) return false;
+        // Median split on the widest centroid axis (coincident centroids, or depth budget exhausted).
+        int a = 0;
+        float w = -1.0f;
+        for (int k = 0; k < 3; ++k) {
+            float e = cbox.hi[k] - cbox.lo[k];
+            if (e > w) {
+                w = e;
+                a = k;
+            }
+        }
+        mid = begin + count / 2;
+        std::nth_element(refs.begin() + begin, refs.begin() + mid, refs.begin() + end, [a](const Ref& x, const Ref& y) { return x.c[a] < y.c[a]; });
+        return true;
+    };
+
+    if (n <= kMaxLeafPrims) {
+        Box box, cbox;
+        bounds_of(0, n, box, cbox);
+        make_leaf(Task{0, n, 1, 0, 0}, box);
+        return out;
+    }
+    {
+        Box box, cbox;
+        bounds_of(0, n, box, cbox);
+        uint32_t mid = 0;
+        split(0, n, 0, box, cbox, mid); // n > kMaxLeafPrims: always splits
+        stack.push_back(Task{mid, n, 1, 0, 1});
+        stack.push_back(Task{0, mid, 1, 0, 0});
+    }
+    while (!stack.empty()) {
+        Task t = stack.back();
+        stack.pop_back();
+        Box box, cbox;
+        bounds_of(t.begin, t.end, box, cbox);
+        uint32_t mid = 0;
+        if (!split(t.begin, t.end, t.depth, box, cbox, mid)) {
+            make_leaf(t, box);
+            continue;
+        }
+        int32_t id = (int32_t)out.nodes.size();
+        out.nodes.push_back(empty_node());
+        set_child(t.parent, t.slot, id, box);
+        stack.push_back(Task{mid, t.end, t.depth + 1, id, 1});
+        stack.push_back(Task{t.begin, mid, t.depth + 1, id, 0});
+    }
+    return out;
+}
+
+} // namespace pyr

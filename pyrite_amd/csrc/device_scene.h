@@ -1,0 +1,106 @@
+// device_scene.h -- layout of the frozen scene in HBM, shared by the host packer (api.cpp) and the kernels.
+#pragma once
+#include <cstdint>
+
+#include "../../include/pyrite_gpu.h"
+
+namespace pyr {
+
+// One primitive in BVH leaf order, 48 bytes = three float4 (one dwordx4 load each):
+//   triangle: a = (v1.xyz, shape), b = (edge1.xyz, 0), c = (edge2.xyz, 0)   [edges as shapes/mod.rs:44-45]
+//   sphere:   a = (centre.xyz, shape), b = (radius, 0, 0, 0), c = 0
+// `shape` = (PyrShapeKind << 30) | index, stored as float bits.
+struct DevPrim {
+    float a[4], b[4], c[4];
+};
+
+// Shading record of a triangle, indexed by ORIGINAL triangle index, 48 bytes:
+//   (n1.xyz, material), (n2.xyz, 0), (n3.xyz, 0).  Texture coordinates are not uploaded: only texture opcodes read
+//   them and those are out of scope.
+struct DevTriShade {
+    float n1[4], n2[4], n3[4];
+};
+
+// Lamp with everything Lamp::sample (lamp.rs:23-82) touches pre-gathered.
+struct DevLamp {
+    uint32_t kind, shape_kind, shape_index, color_program;
+    float v[3]; // direction / position / sphere centre
+    float width; // directional: cos half angle; sphere: radius
+    float p1[3], p2[3], p3[3]; // triangle lamp vertices
+    float n1[3], n2[3], n3[3]; // triangle lamp vertex normals
+    float area;                // Shape::surface_area
+    uint32_t material;
+};
+
+enum FastProgram : uint32_t {
+    FAST_NONE = 0,         // run the interpreter
+    FAST_SPECTRUM = 1,     // [SpectrumValue(wavelength)]
+    FAST_SPECTRUM_MUL = 2, // [SpectrumValue(wavelength), NumberValue(c), Binary Mul]  == spectrum * c
+    FAST_MUL_SPECTRUM = 3  // [NumberValue(c), SpectrumValue(wavelength), Binary Mul]  == c * spectrum
+};
+
+struct DevProgram {
+    uint32_t kind; // PyrProgramKind
+    float constant;
+    uint32_t first_instr, num_instrs;
+    uint32_t output_kind, output_reg;
+    uint32_t fast;            // FastProgram
+    uint32_t fast_spectrum;   // spectrum id of the fast forms
+    float fast_scale;         // c of the fast forms
+    uint32_t reads_wavelength; // some executed operand is Input(Wavelength): ProbabilityInput::wavelength_used
+};
+
+struct DevScene {
+    const float* nodes;  // Node64[], 16 floats each
+    const float* prims;  // DevPrim[], 12 floats each
+    const float* tri_shade; // DevTriShade[]
+    const float* spheres;   // [n][4] centre, radius (original order)
+    const uint32_t* sphere_material;
+    const float* planes;    // [n][8]
+    const uint32_t* plane_material;
+    const DevLamp* lamps;
+    const PyrMaterial* materials;
+    const PyrComponent* components;
+    const DevProgram* programs;
+    const PyrInstr* instrs;
+    const PyrSpectrum* spectra;
+    const float* spectrum_data;
+    const float* rgb_basis;
+    uint32_t num_planes, num_lamps;
+    uint32_t rgb_count;
+    float rgb_min, rgb_max;
+    uint32_t sky_program;
+    uint32_t stack_depth; // LDS stack entries per lane = BVH max depth
+};
+
+// Everything one render launch needs besides the scene.
+struct RenderLaunch {
+    PyrCamera camera;
+    PyrFilmDesc film;
+    uint32_t bounces, light_samples, spectrum_samples, tile_size, pixel_samples;
+    uint32_t tiles_x, tiles_y;
+    // A chunk is 64 consecutive iterations of one tile. Chunks are numbered over the whole image in raster tile order;
+    // every tile of a row has chunks_interior chunks except the last column (chunks_right); the last tile row uses
+    // chunks_bottom / chunks_corner. [chunk_begin, chunk_end) is the range this launch renders.
+    uint32_t chunks_interior, chunks_right, chunks_bottom, chunks_corner;
+    uint32_t chunk_begin, chunk_end;
+    uint32_t film_row_begin, film_row_count;
+    uint64_t seed;
+    float grains_per_wavelength; // bins / wl_width (film.rs:38)
+    PyrGrain* film_out;
+    unsigned long long* counters; // 9 words (PyrCounters order) or nullptr
+};
+
+struct IntersectLaunch {
+    const float* rays;
+    PyrHit* hits;
+    uint32_t n;
+    unsigned long long* counters;
+};
+
+// launchers (kernels.hip)
+int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);
+int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);
+const char* kernels_last_error();
+
+} // namespace pyr

@@ -1,0 +1,1086 @@
+// kernels.hip -- CDNA4 (gfx950) kernels for Pyrite's camera-to-light integrator.
+//
+// What runs here is the whole of render_tile's per-sample loop (pyrite/src/renderer/simple.rs:78-140) and everything it
+// calls: sample generation, tracer::trace (tracer.rs:208-345), trace_direct (:347-442), the spectral fold `contribute`
+// (renderer/algorithm.rs:14-100, applied online bounce by bounce) and Film::expose (film.rs:89-95).
+//
+// Execution model (DESIGN.md "Kernel"): one persistent launch; a wave walks a strided sequence of 64-iteration chunks
+// and every LANE owns one sample at a time and refills itself as soon as its path ends (no lane waits for the wave's
+// longest path). Per lane: path state in VGPRs, the S spectral companions (wavelength / brightness / reflectance) and
+// the traversal stack in LDS laid out [entry][lane] (bank-conflict free), BVH nodes fetched as 4 x dwordx4 (64 B, both
+// children's boxes), leaf primitives as 3 x dwordx4. Film exposure is two no-return global_atomic_add_f32 per exposure.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "device_scene.h"
+
+namespace pyr {
+
+namespace {
+thread_local std::string g_kernel_error;
+}
+const char* kernels_last_error() { return g_kernel_error.c_str(); }
+
+#define DEV __device__ __forceinline__
+
+constexpr int BLOCK = 256;
+constexpr float DIST_EPSILON = 0.0001f; // math.rs:4
+constexpr float PI_F = 3.14159265358979323846f;
+#define PYR_INF __builtin_huge_valf()
+
+// ------------------------------------------------------------------------------------------------ vectors
+struct f3 {
+    float x, y, z;
+};
+DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+DEV f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEV f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEV float magnitude(f3 a) { return sqrtf(dot(a, a)); }
+DEV f3 normalize_to(f3 a, float m) { return a * (m / magnitude(a)); } // cgmath: v * (m / |v|)
+DEV f3 normalize(f3 a) { return normalize_to(a, 1.0f); }
+DEV f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// Transcendentals through f64, rounded once: the correctly rounded f32 value (up to ~1e-8 double-rounding cases), the
+// same definition oracle/oracle.cpp uses, so directions agree bit for bit with the CPU restatement. The file is built
+// with -ffp-contract=off for the same reason: the reference (Rust) never fuses a*b+c.
+DEV float sin32(float x) { return (float)sin((double)x); }
+DEV float cos32(float x) { return (float)cos((double)x); }
+DEV float acos32(float x) { return (float)acos((double)x); }
+DEV float exp32(float x) { return (float)exp((double)x); }
+
+// ------------------------------------------------------------------------------------------------ RNG
+// xorshift128 (rand_xorshift 0.3.0) per (seed, tile, iteration); distributions of rand 0.8.5. Same stream layout as
+// oracle/oracle.cpp (DESIGN.md "RNG").
+struct Rng {
+    uint32_t x, y, z, w;
+};
+DEV uint32_t rng_u32(Rng& r) {
+    uint32_t t = r.x ^ (r.x << 11);
+    r.x = r.y;
+    r.y = r.z;
+    r.z = r.w;
+    r.w = r.w ^ (r.w >> 19) ^ (t ^ (t >> 8));
+    return r.w;
+}
+DEV uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+DEV Rng rng_seed(uint64_t seed, uint32_t tile, uint64_t iteration) {
+    uint64_t counter = ((uint64_t)tile << 40) ^ iteration;
+    uint64_t a = splitmix64(seed ^ splitmix64(counter));
+    uint64_t b = splitmix64(a);
+    Rng r{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    if ((r.x | r.y | r.z | r.w) == 0) r.w = 1;
+    return r;
+}
+DEV float rng_f32(Rng& r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
+// UniformFloat::sample_single. The multiply-add is written with round-to-nearest intrinsics so that it is never fused:
+// the sampled wavelength decides the film bin and must equal the oracle's bit for bit.
+DEV float rng_range_f32(Rng& r, float low, float high) {
+    float scale = __fsub_rn(high, low);
+    for (;;) {
+        float value0_1 = __uint_as_float((rng_u32(r) >> 9) | 0x3F800000u) - 1.0f;
+        float res = __fadd_rn(__fmul_rn(value0_1, scale), low);
+        if (res < high) return res;
+        scale = __uint_as_float(__float_as_uint(scale) - 1u);
+    }
+}
+// UniformInt<usize>::sample_single: 64-bit draw, widening multiply by `n` (< 2^32), rejection zone.
+DEV uint32_t rng_range_usize(Rng& r, uint32_t n) {
+    uint64_t range = n;
+    uint64_t zone = (range << __builtin_clzll(range)) - 1;
+    for (;;) {
+        uint64_t lo32 = rng_u32(r);
+        uint64_t hi32 = rng_u32(r);
+        uint64_t p0 = lo32 * range;           // < 2^64
+        uint64_t p1 = hi32 * range;           // contributes p1 << 32
+        uint64_t lo = p0 + (p1 << 32);        // low 64 bits of v * range
+        uint64_t carry = lo < p0 ? 1 : 0;
+        uint64_t hi = (p1 >> 32) + carry;     // high 64 bits
+        if (lo <= zone) return (uint32_t)hi;
+    }
+}
+// SliceRandom::choose -> gen_range(0..n as u32).
+DEV uint32_t rng_choose(Rng& r, uint32_t n) {
+    uint32_t zone = (n << __builtin_clz(n)) - 1;
+    for (;;) {
+        uint32_t v = rng_u32(r);
+        uint64_t m = (uint64_t)v * n;
+        if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ counters
+struct Counters {
+    uint32_t samples, extension_rays, shadow_rays, box_tests, triangle_tests, sphere_tests, plane_tests, shaded_hits, exposures;
+};
+template <bool COUNT>
+DEV void flush_counters(const Counters& c, unsigned long long* out) {
+    if constexpr (COUNT) {
+        const uint32_t* v = reinterpret_cast<const uint32_t*>(&c);
+        for (int k = 0; k < 9; ++k) {
+            // wave reduction, then one atomic per wave
+            unsigned long long s = v[k];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&out[k], s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ spectra & the VM
+// Spectrum::get, project/spectra.rs:30-58 (+ Interpolated::get, math.rs:22-72).
+DEV float spectrum_get(const DevScene& S, uint32_t id, float w) {
+    const PyrSpectrum sp = S.spectra[id];
+    const float* data = S.spectrum_data + sp.offset;
+    if (sp.format == PYR_SPECTRUM_ARRAY) {
+        if (sp.count == 0) return 0.0f;
+        if (w <= sp.min) return data[0];
+        if (w >= sp.max) return data[sp.count - 1];
+        float normalized = (w - sp.min) / (sp.max - sp.min);
+        float float_index = normalized * ((float)sp.count - 1.0f);
+        float min_float_index = truncf(float_index);
+        uint32_t i0 = (uint32_t)min_float_index;
+        float mix = float_index - min_float_index;
+        return data[i0] * (1.0f - mix) + data[i0 + 1] * mix;
+    }
+    uint32_t count = sp.count;
+    if (count == 0) return 0.0f;
+    uint32_t mn = 0, mx = count - 1;
+    if (data[2 * mn] >= w) return 0.0f;
+    if (data[2 * mx] <= w) return 0.0f;
+    while (mx > mn + 1) {
+        uint32_t check = (mx + mn) / 2;
+        float cx = data[2 * check];
+        if (cx == w) return data[2 * check + 1];
+        if (cx > w)
+            mx = check;
+        else
+            mn = check;
+    }
+    float min_x = data[2 * mn], min_y = data[2 * mn + 1];
+    float max_x = data[2 * mx], max_y = data[2 * mx + 1];
+    if (w < min_x || w > max_x) return 0.0f;
+    return min_y + (max_y - min_y) * ((w - min_x) / (max_x - min_x));
+}
+
+// math.rs:75-96 / :167-175
+DEV float schlick(float n1, float n2, f3 normal, f3 incident) {
+    float cos_psi = -dot(normal, incident);
+    float r0 = (n1 - n2) / (n1 + n2);
+    if (n1 > n2) {
+        float n = n1 / n2;
+        float sin_t2 = n * n * (1.0f - cos_psi * cos_psi);
+        if (sin_t2 > 1.0f) return 1.0f;
+        cos_psi = sqrtf(1.0f - sin_t2);
+    }
+    float inv_cos = 1.0f - cos_psi;
+    return r0 * r0 + (1.0f - r0 * r0) * inv_cos * inv_cos * inv_cos * inv_cos * inv_cos;
+}
+DEV float fresnel(float ior, float env_ior, f3 normal, f3 incident) {
+    if (dot(incident, normal) < 0.0f) return schlick(env_ior, ior, normal, incident);
+    return schlick(ior, env_ior, -normal, incident);
+}
+// math.rs:177-182
+DEV float blackbody(float wavelength, float temperature) {
+    float wl = wavelength * 1.0e-9f;
+    float a2 = wl * wl;
+    float a4 = a2 * a2;
+    float power_term = 3.74183e-16f * (1.0f / (wl * a4));
+    return power_term / (exp32(1.4388e-2f / (wl * temperature)) - 1.0f);
+}
+
+struct VmInput { // RenderContext / ProbabilityInput
+    float wavelength;
+    f3 normal, incident;
+};
+
+// The register interpreter (program/execution_context.rs:69-283). Programs are pure functions of their input, so the
+// reference's memoised re-run (execute only wavelength-dependent instructions) and a full run give the same value.
+__device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgram& p, const VmInput& in) {
+    float num[PYR_MAX_NUMBER_REGISTERS];
+    float vec[PYR_MAX_VECTOR_REGISTERS][4];
+    float rgb[PYR_MAX_RGB_REGISTERS][4];
+    auto value = [&](const PyrOperand& o) -> float {
+        if (o.kind == PYR_OPERAND_CONSTANT) return __uint_as_float(o.bits);
+        if (o.kind == PYR_OPERAND_INPUT) return in.wavelength;
+        return num[o.bits & (PYR_MAX_NUMBER_REGISTERS - 1)];
+    };
+    auto vinput = [&](uint32_t which, float out[4]) {
+        f3 v = which == PYR_INPUT_NORMAL ? in.normal : (which == PYR_INPUT_INCIDENT ? in.incident : mk(0, 0, 0));
+        out[0] = v.x;
+        out[1] = v.y;
+        out[2] = v.z;
+        out[3] = 0.0f;
+    };
+    auto binop = [](uint32_t op, float l, float r) -> float {
+        switch (op) {
+        case PYR_BIN_ADD: return l + r;
+        case PYR_BIN_SUB: return l - r;
+        case PYR_BIN_MUL: return l * r;
+        default: return l / r;
+        }
+    };
+    for (uint32_t k = 0; k < p.num_instrs; ++k) {
+        const PyrInstr& ins = S.instrs[p.first_instr + k];
+        const uint32_t out = ins.output;
+        switch (ins.op) {
+        case PYR_OP_NUMBER: num[out & 15] = __uint_as_float(ins.x.bits); break;
+        case PYR_OP_VECTOR: {
+            float x = value(ins.x), y = value(ins.y), z = value(ins.z), w = value(ins.w);
+            float* v = vec[out & 3];
+            v[0] = x, v[1] = y, v[2] = z, v[3] = w;
+            break;
+        }
+        case PYR_OP_RGB: {
+            float r = value(ins.x), g = value(ins.y), b = value(ins.z);
+            float* v = rgb[out & 3];
+            v[0] = r, v[1] = g, v[2] = b, v[3] = 1.0f;
+            break;
+        }
+        case PYR_OP_SPECTRUM: num[out & 15] = spectrum_get(S, ins.a, value(ins.x)); break;
+        case PYR_OP_RGB_SPECTRUM: {
+            float wl = value(ins.x);
+            const float* c = rgb[ins.a & 3];
+            float resp[3] = {0, 0, 0};
+            uint32_t count = S.rgb_count;
+            if (count > 0) {
+                const float* d = S.rgb_basis;
+                if (wl <= S.rgb_min) {
+                    for (int j = 0; j < 3; ++j) resp[j] = d[j];
+                } else if (wl >= S.rgb_max) {
+                    for (int j = 0; j < 3; ++j) resp[j] = d[3 * (count - 1) + j];
+                } else {
+                    float normalized = (wl - S.rgb_min) / (S.rgb_max - S.rgb_min);
+                    float fi = normalized * ((float)count - 1.0f);
+                    float fmin_ = truncf(fi);
+                    uint32_t i0 = (uint32_t)fmin_;
+                    float mix = fi - fmin_;
+                    for (int j = 0; j < 3; ++j) resp[j] = d[3 * i0 + j] * (1.0f - mix) + d[3 * (i0 + 1) + j] * mix;
+                }
+            }
+            num[out & 15] = c[0] * resp[0] + c[1] * resp[1] + c[2] * resp[2];
+            break;
+        }
+        case PYR_OP_FRESNEL: {
+            float ior = value(ins.x), env = value(ins.y);
+            float nn[4], ii[4];
+            vinput(ins.a, nn);
+            vinput(ins.b, ii);
+            num[out & 15] = fresnel(ior, env, mk(nn[0], nn[1], nn[2]), mk(ii[0], ii[1], ii[2]));
+            break;
+        }
+        case PYR_OP_BLACKBODY: {
+            float wl = value(ins.x), temp = value(ins.y);
+            num[out & 15] = blackbody(wl, temp);
+            break;
+        }
+        case PYR_OP_RGB_TO_VECTOR: {
+            const float* c = rgb[ins.a & 3];
+            float* v = vec[out & 3];
+            for (int j = 0; j < 4; ++j) v[j] = (c[j] * 2.0f) - 1.0f;
+            break;
+        }
+        case PYR_OP_MIX: {
+            float amount = fmaxf(fminf(value(ins.x), 1.0f), 0.0f);
+            if (ins.value_type == PYR_VT_NUMBER) {
+                float l = num[ins.a & 15], r = num[ins.b & 15];
+                num[out & 15] = l * (1.0f - amount) + r * amount;
+            } else {
+                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & 3] : rgb[ins.a & 3];
+                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & 3] : rgb[ins.b & 3];
+                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & 3] : rgb[out & 3];
+                float t[4];
+                for (int j = 0; j < 4; ++j) t[j] = l[j] + (r[j] - l[j]) * amount;
+                for (int j = 0; j < 4; ++j) o[j] = t[j];
+            }
+            break;
+        }
+        case PYR_OP_BINARY: {
+            if (ins.value_type == PYR_VT_NUMBER) {
+                num[out & 15] = binop(ins.operator_, num[ins.a & 15], num[ins.b & 15]);
+            } else {
+                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & 3] : rgb[ins.a & 3];
+                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & 3] : rgb[ins.b & 3];
+                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & 3] : rgb[out & 3];
+                float t[4];
+                for (int j = 0; j < 4; ++j) t[j] = binop(ins.operator_, l[j], r[j]);
+                for (int j = 0; j < 4; ++j) o[j] = t[j];
+            }
+            break;
+        }
+        case PYR_OP_CLAMP: {
+            float v = value(ins.x), mn = value(ins.y), mx = value(ins.z);
+            num[out & 15] = fmaxf(fminf(v, mx), mn);
+            break;
+        }
+        default: break;
+        }
+    }
+    if (p.output_kind == PYR_OUTPUT_NUMBER) return num[p.output_reg & 15];
+    return vec[p.output_reg & 3][0];
+}
+
+// ExecutionContext::run (execution_context.rs:29-56) with the three shapes every Cornell-family program has short-cut.
+DEV float run_program(const DevScene& S, uint32_t id, const VmInput& in) {
+    const DevProgram p = S.programs[id];
+    if (p.kind == PYR_PROGRAM_CONSTANT) return p.constant;
+    switch (p.fast) {
+    case FAST_SPECTRUM: return spectrum_get(S, p.fast_spectrum, in.wavelength);
+    case FAST_SPECTRUM_MUL: return spectrum_get(S, p.fast_spectrum, in.wavelength) * p.fast_scale;
+    case FAST_MUL_SPECTRUM: return p.fast_scale * spectrum_get(S, p.fast_spectrum, in.wavelength);
+    default: return run_interpreter(S, p, in);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sampling helpers (math.rs)
+DEV f3 ortho(f3 v) { // math.rs:98-114
+    f3 unit;
+    if (fabsf(v.x) < DIST_EPSILON)
+        unit = mk(1, 0, 0);
+    else if (fabsf(v.y) < DIST_EPSILON)
+        unit = mk(0, 1, 0);
+    else if (fabsf(v.z) < DIST_EPSILON)
+        unit = mk(0, 0, 1);
+    else
+        unit = mk(-v.y, v.x, 0.0f);
+    return cross(v, unit);
+}
+DEV f3 sample_cone(Rng& rng, f3 direction, float cos_half) { // math.rs:125-137
+    f3 o1 = normalize(ortho(direction));
+    f3 o2 = normalize(cross(direction, o1));
+    float r1 = PI_F * 2.0f * rng_f32(rng);
+    float r2 = cos_half + (1.0f - cos_half) * rng_f32(rng);
+    float oneminus = sqrtf(1.0f - r2 * r2);
+    return o1 * cos32(r1) * oneminus + o2 * sin32(r1) * oneminus + direction * r2;
+}
+DEV float solid_angle(float cos_half) { return cos_half >= 1.0f ? 0.0f : 2.0f * PI_F * (1.0f - cos_half); } // :139-145
+DEV f3 sample_sphere(Rng& rng) { // math.rs:147-153
+    float u = rng_f32(rng);
+    float v = rng_f32(rng);
+    float theta = 2.0f * PI_F * u;
+    float phi = acos32(2.0f * v - 1.0f);
+    float sp = sin32(phi);
+    return mk(sp * cos32(theta), sp * sin32(theta), cos32(phi));
+}
+DEV f3 sample_hemisphere(Rng& rng, f3 direction) { // math.rs:155-164
+    f3 s = sample_sphere(rng);
+    f3 x = normalize_to(ortho(direction), s.x);
+    f3 y = normalize_to(cross(x, direction), s.y);
+    f3 z = normalize_to(direction, fabsf(s.z));
+    return x + y + z;
+}
+
+// ------------------------------------------------------------------------------------------------ primitives
+// shapes/mod.rs:75-119, same operation order as the reference.
+DEV bool triangle_test(f3 v1, f3 e1, f3 e2, f3 o, f3 d, float& dist, float& u, float& v) {
+    f3 p = cross(d, e2);
+    float det = dot(e1, p);
+    if (det > -DIST_EPSILON && det < DIST_EPSILON) return false;
+    float inv_det = 1.0f / det;
+    f3 t = o - v1;
+    u = dot(t, p) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q = cross(t, e1);
+    v = dot(d, q) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    dist = dot(e2, q) * inv_det;
+    return dist > DIST_EPSILON;
+}
+// shapes/mod.rs:57-74 via collision::Sphere (oracle.cpp sphere_intersect).
+DEV bool sphere_test(f3 center, float radius, f3 o, f3 d, float& dist, f3& point) {
+    f3 l = center - o;
+    float tca = dot(l, d);
+    if (tca < 0.0f) return false;
+    float d2 = dot(l, l) - tca * tca;
+    if (d2 > radius * radius) return false;
+    float thc = sqrtf(radius * radius - d2);
+    point = o + d * (tca - thc);
+    dist = magnitude(point - o);
+    return true;
+}
+// shapes/mod.rs:441-452 (oracle.cpp plane_intersect).
+DEV bool plane_test(f3 origin, f3 normal, f3 o, f3 d, float& dist, f3& point) {
+    float t = (dot(origin, normal) - dot(o, normal)) / dot(d, normal);
+    if (!(t >= 0.0f)) return false;
+    point = o + d * t;
+    dist = magnitude(point - o);
+    return true;
+}
+
+struct Hit {
+    float t;
+    uint32_t shape; // PYR_HIT_NONE or (kind << 30) | index
+    float u, v;
+};
+
+// math.rs:184-207: entry distance of the ray into a box, or -1 when it misses.
+DEV float slab(f3 lo, f3 hi, f3 o, f3 inv) {
+    float t1 = (lo.x - o.x) * inv.x, t2 = (hi.x - o.x) * inv.x;
+    float tmin = fminf(t1, t2), tmax = fmaxf(t1, t2);
+    t1 = (lo.y - o.y) * inv.y, t2 = (hi.y - o.y) * inv.y;
+    tmin = fmaxf(tmin, fminf(t1, t2)), tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = (lo.z - o.z) * inv.z, t2 = (hi.z - o.z) * inv.z;
+    tmin = fmaxf(tmin, fminf(t1, t2)), tmax = fminf(tmax, fmaxf(t1, t2));
+    return (tmax >= tmin && tmax >= 0.0f) ? fmaxf(tmin, 0.0f) : -1.0f;
+}
+
+// World::intersect (world.rs:273-299). SHADOW = false: closest hit with DIST_EPSILON < d < closest.
+// SHADOW = true: answers trace_direct's visibility question (tracer.rs:381-389) -- "is there a hit with
+// d > eps and d*d < limit" -- and returns as soon as one is found (equivalent to testing the closest hit, because
+// d -> d*d is monotonic). `limit` = lamp_distance^2 - eps, or +inf when the lamp has no distance.
+template <bool COUNT, bool SHADOW>
+DEV bool traverse(const DevScene& S, f3 o, f3 d, float limit, Hit& hit, int* stack, Counters& cnt) {
+    float closest = PYR_INF;
+    hit.shape = PYR_HIT_NONE;
+    hit.t = PYR_INF;
+    hit.u = hit.v = 0.0f;
+    for (uint32_t i = 0; i < S.num_planes; ++i) {
+        const float* pl = S.planes + 8 * i;
+        float dist;
+        f3 point;
+        if (COUNT) cnt.plane_tests++;
+        if (plane_test(ld3(pl), ld3(pl + 3), o, d, dist, point)) {
+            if (SHADOW) {
+                if (dist > DIST_EPSILON && dist * dist < limit) return true;
+            } else if (dist > DIST_EPSILON && dist < closest) {
+                closest = dist;
+                hit.t = dist;
+                hit.shape = ((uint32_t)PYR_SHAPE_PLANE << 30) | i;
+            }
+        }
+    }
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float4* nodes = reinterpret_cast<const float4*>(S.nodes);
+    const float4* prims = reinterpret_cast<const float4*>(S.prims);
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        const float4 n0 = nodes[4 * node + 0], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+        if (COUNT) cnt.box_tests += 2;
+        float e0 = slab(mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z), o, inv);
+        float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), o, inv);
+        bool h0, h1;
+        if (SHADOW) {
+            h0 = e0 >= 0.0f && e0 * e0 < limit;
+            h1 = e1 >= 0.0f && e1 * e1 < limit;
+        } else {
+            h0 = e0 >= 0.0f && e0 < closest; // bvh.rs:213: skip when distance >= max_distance
+            h1 = e1 >= 0.0f && e1 < closest;
+        }
+        const int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+        int next;
+        if (h0 && h1) {
+            bool swap = e1 < e0;
+            next = swap ? c1 : c0;
+            stack[sp * BLOCK] = swap ? c0 : c1;
+            sp++;
+        } else if (h0) {
+            next = c0;
+        } else if (h1) {
+            next = c1;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            next = stack[sp * BLOCK];
+        }
+        bool done = false;
+        while (next < 0) {
+            uint32_t code = (uint32_t)(-1 - next);
+            uint32_t first = code >> 3, count = code & 7u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 a = prims[3 * (first + k) + 0], b = prims[3 * (first + k) + 1];
+                const uint32_t shape = __float_as_uint(a.w);
+                float dist, u = 0.0f, v = 0.0f;
+                bool ok;
+                if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
+                    const float4 c = prims[3 * (first + k) + 2];
+                    if (COUNT) cnt.triangle_tests++;
+                    ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, dist, u, v);
+                } else {
+                    f3 point;
+                    if (COUNT) cnt.sphere_tests++;
+                    ok = sphere_test(mk(a.x, a.y, a.z), b.x, o, d, dist, point);
+                }
+                if (ok) {
+                    if (SHADOW) {
+                        if (dist > DIST_EPSILON && dist * dist < limit) return true;
+                    } else if (dist > DIST_EPSILON && dist < closest) {
+                        closest = dist;
+                        hit.t = dist;
+                        hit.shape = shape;
+                        hit.u = u;
+                        hit.v = v;
+                    }
+                }
+            }
+            if (sp == 0) {
+                done = true;
+                break;
+            }
+            sp--;
+            next = stack[sp * BLOCK];
+        }
+        if (done) break;
+        node = next;
+    }
+    return hit.shape != PYR_HIT_NONE;
+}
+
+// ------------------------------------------------------------------------------------------------ intersect kernel
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectLaunch L) {
+    extern __shared__ int lds_stack[];
+    int* stack = lds_stack + threadIdx.x;
+    Counters cnt{};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < L.n; i += gridDim.x * BLOCK) {
+        const float* r = L.rays + 6 * (size_t)i;
+        Hit hit;
+        traverse<COUNT, false>(S, ld3(r), ld3(r + 3), 0.0f, hit, stack, cnt);
+        PyrHit out;
+        out.distance = hit.t;
+        out.shape = hit.shape;
+        out.u = hit.u;
+        out.v = hit.v;
+        L.hits[i] = out;
+    }
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ------------------------------------------------------------------------------------------------ camera / film mapping
+struct TileArea {
+    float from_x, from_y, size_x, size_y;
+};
+// Camera::to_view_area, cameras.rs:57-68 -- unfused so tile rectangles equal the oracle's bit for bit.
+DEV TileArea to_view_area(uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t width, uint32_t height) {
+    float iw = (float)width, ih = (float)height;
+    float half_max = __fmul_rn(fmaxf(iw, ih), 0.5f);
+    TileArea a;
+    a.from_x = __fdiv_rn(__fadd_rn((float)x, -__fmul_rn(iw, 0.5f)), half_max);
+    a.from_y = __fdiv_rn(__fadd_rn((float)y, -__fmul_rn(ih, 0.5f)), half_max);
+    a.size_x = __fdiv_rn((float)w, half_max);
+    a.size_y = __fdiv_rn((float)h, half_max);
+    return a;
+}
+DEV f3 transform_point(const float* m, f3 p) { // cgmath Matrix4 * (p, 1), then / w
+    float x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+    float y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+    float z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+    float w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
+    float inv = 1.0f / w;
+    return mk(x * inv, y * inv, z * inv);
+}
+DEV f3 transform_vector(const float* m, f3 v) {
+    return mk(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z, m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+// Rust `as usize`: saturating, NaN -> 0 (values here are far below 2^32).
+DEV uint32_t f32_as_index(float f) { return f > 0.0f ? (f >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)f) : 0u; }
+
+// Film::expose (film.rs:89-95): wavelength_to_grain (:85-87), AspectRatio::to_pixel (:233-246), Grain::increment (:145-162)
+// as two no-return float atomics (the reference's 5-try CAS may drop samples under contention; atomics never do).
+template <bool COUNT>
+DEV void film_expose(const RenderLaunch& L, float px, float py, float wavelength, float brightness, Counters& cnt) {
+    const uint32_t width = L.film.width, height = L.film.height, bins = L.film.bins;
+    uint32_t grain = f32_as_index(__fmul_rn(__fsub_rn(wavelength, L.film.wl_start), L.grains_per_wavelength));
+    grain = grain < bins - 1 ? grain : bins - 1;
+    uint32_t x, y;
+    if (width >= height) {
+        float size = (float)width, ratio = __fdiv_rn((float)height, (float)width);
+        if (!(fabsf(py) <= ratio)) return;
+        x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, 1.0f)), 0.5f));
+        y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, ratio)), 0.5f));
+    } else {
+        float size = (float)height, ratio = __fdiv_rn((float)width, (float)height);
+        if (!(fabsf(px) <= ratio)) return;
+        x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, ratio)), 0.5f));
+        y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, 1.0f)), 0.5f));
+    }
+    if (x >= width || y >= height) return;
+    if (y < L.film_row_begin || y >= L.film_row_begin + L.film_row_count) return;
+    size_t index = ((size_t)x + (size_t)(y - L.film_row_begin) * width) * bins + grain;
+    float* g = reinterpret_cast<float*>(L.film_out + index);
+    atomicAdd(g, brightness); // value * weight with weight == 1 (simple.rs:95-98)
+    atomicAdd(g + 1, 1.0f);
+    if (COUNT) cnt.exposures++;
+}
+
+// ------------------------------------------------------------------------------------------------ the integrator
+// LDS: [3 * S][BLOCK] floats (wavelength, brightness, reflectance of the S-1 companions; slot S-1 is scratch during
+// sample generation) followed by [stack_depth][BLOCK] ints.
+struct Spectral {
+    float* base;
+    uint32_t s;
+    DEV float& wl(uint32_t k) { return base[(0 * s + k) * BLOCK]; }
+    DEV float& bright(uint32_t k) { return base[(1 * s + k) * BLOCK]; }
+    DEV float& refl(uint32_t k) { return base[(2 * s + k) * BLOCK]; }
+};
+
+// Surface normal at a hit (SurfacePoint::get_surface_data, shapes/mod.rs:484-494) and the material id.
+DEV void surface_at(const DevScene& S, const Hit& hit, f3 o, f3 d, f3& position, f3& normal, uint32_t& material) {
+    const uint32_t kind = hit.shape >> 30, index = hit.shape & 0x3FFFFFFFu;
+    if (kind == PYR_SHAPE_TRIANGLE) {
+        const float4* sh = reinterpret_cast<const float4*>(S.tri_shade) + 3 * (size_t)index;
+        const float4 a = sh[0], b = sh[1], c = sh[2];
+        float w = 1.0f - (hit.u + hit.v);
+        normal = normalize(mk(a.x, a.y, a.z) * w + mk(b.x, b.y, b.z) * hit.u + mk(c.x, c.y, c.z) * hit.v); // Normal::on_triangle :550-558
+        material = __float_as_uint(a.w);
+        position = o + d * hit.t;
+    } else if (kind == PYR_SHAPE_SPHERE) {
+        const float4 sp = reinterpret_cast<const float4*>(S.spheres)[index];
+        float dist;
+        sphere_test(mk(sp.x, sp.y, sp.z), sp.w, o, d, dist, position); // the intersection point collision returned
+        normal = normalize(position - mk(sp.x, sp.y, sp.z));
+        material = S.sphere_material[index];
+    } else {
+        const float* pl = S.planes + 8 * index;
+        float dist;
+        plane_test(ld3(pl), ld3(pl + 3), o, d, dist, position);
+        normal = ld3(pl + 3);
+        material = S.plane_material[index];
+    }
+}
+
+// materials/refractive.rs:47-91
+DEV void refract(float ior, float env_ior, f3 in_direction, f3 normal, Rng& rng, f3& out, float& prob) {
+    f3 nl = dot(normal, in_direction) < 0.0f ? normal : -normal;
+    f3 reflected = in_direction - (normal * 2.0f * dot(normal, in_direction));
+    bool into = dot(normal, nl) > 0.0f;
+    float nnt = into ? env_ior / ior : ior / env_ior;
+    float ddn = dot(in_direction, nl);
+    float cos2t = 1.0f - nnt * nnt * (1.0f - ddn * ddn);
+    if (cos2t < 0.0f) {
+        out = reflected;
+        prob = 1.0f;
+        return;
+    }
+    float s = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
+    f3 tdir = normalize(in_direction * nnt - normal * s);
+    float a = ior - env_ior, b = ior + env_ior;
+    float r0 = a * a / (b * b);
+    float c = 1.0f - (into ? -ddn : dot(tdir, normal));
+    float re = r0 + (1.0f - r0) * c * c * c * c * c;
+    float tr = 1.0f - re;
+    float p = 0.25f + 0.5f * re;
+    if (rng_f32(rng) < p) {
+        out = reflected;
+        prob = re / p;
+    } else {
+        out = tdir;
+        prob = tr / (1.0f - p);
+    }
+}
+
+struct LampSample { // lamp.rs:116-130
+    f3 direction;
+    float sq_distance; // < 0: None
+    bool physical;
+    f3 normal;
+    uint32_t material, color;
+    float weight;
+};
+
+// Lamp::sample (lamp.rs:23-82) with Shape::sample_towards / sample_point / solid_angle_towards (shapes/mod.rs:166-271).
+DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
+    LampSample ls;
+    ls.physical = false;
+    ls.material = 0;
+    ls.color = lamp.color_program;
+    ls.normal = mk(0, 0, 0);
+    if (lamp.kind == PYR_LAMP_DIRECTIONAL) {
+        f3 direction = ld3(lamp.v);
+        ls.direction = lamp.width > 0.0f ? sample_cone(rng, direction, lamp.width) : direction;
+        ls.sq_distance = -1.0f;
+        ls.weight = 1.0f;
+    } else if (lamp.kind == PYR_LAMP_POINT) {
+        f3 v = ld3(lamp.v) - target;
+        float distance = dot(v, v);
+        ls.direction = normalize(v);
+        ls.sq_distance = distance;
+        ls.weight = 4.0f * PI_F / distance;
+    } else if (lamp.shape_kind == PYR_SHAPE_SPHERE) {
+        const f3 center = ld3(lamp.v);
+        const float full_radius = lamp.width;
+        float radius = fmaxf(full_radius - DIST_EPSILON, 0.0f);
+        f3 dir = center - target;
+        float dist2 = dot(dir, dir);
+        f3 position;
+        float distance;
+        if (dist2 > radius * radius) {
+            float cos_theta_max = sqrtf(fmaxf(1.0f - (radius * radius) / dist2, 0.0f));
+            f3 ray_dir = sample_cone(rng, normalize(dir), cos_theta_max);
+            if (!sphere_test(center, full_radius, target, ray_dir, distance, position)) {
+                distance = 0.0f; // "cheat", shapes/mod.rs:229-236
+                position = target;
+            }
+        } else {
+            position = center + sample_sphere(rng) * full_radius;
+            distance = magnitude(position - target);
+        }
+        f3 v = position - target;
+        ls.sq_distance = distance * distance;
+        ls.direction = normalize(v);
+        ls.normal = normalize(position - center);
+        float d2 = dot(center - target, center - target);
+        if (d2 > full_radius * full_radius) {
+            ls.weight = solid_angle(sqrtf(fmaxf(1.0f - (full_radius * full_radius) / d2, 0.0f)));
+        } else {
+            float cos_in = fabsf(dot(ls.normal, -ls.direction));
+            ls.weight = cos_in * lamp.area / ls.sq_distance;
+        }
+        ls.physical = true;
+        ls.material = lamp.material;
+    } else {
+        float u = rng_f32(rng);
+        float v = rng_f32(rng);
+        f3 p1 = ld3(lamp.p1);
+        f3 a = ld3(lamp.p2) - p1, b = ld3(lamp.p3) - p1;
+        if (u + v > 1.0f) {
+            u = 1.0f - u;
+            v = 1.0f - v;
+        }
+        f3 position = p1 + a * u + b * v;
+        f3 delta = position - target;
+        float distance = magnitude(delta);
+        ls.sq_distance = distance * distance;
+        ls.direction = normalize(delta);
+        float w = 1.0f - (u + v);
+        ls.normal = normalize(ld3(lamp.n1) * w + ld3(lamp.n2) * u + ld3(lamp.n3) * v);
+        float cos_in = fabsf(dot(ls.normal, -ls.direction));
+        ls.weight = cos_in * lamp.area / ls.sq_distance;
+        ls.physical = true;
+        ls.material = lamp.material;
+    }
+    return ls;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void render_kernel(DevScene S, RenderLaunch L) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    Spectral spec{lds + threadIdx.x, SS};
+    int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
+    Counters cnt{};
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = BLOCK / 64;
+    const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    uint32_t chunk = L.chunk_begin + wave; // this lane's next chunk; lanes advance independently
+
+    for (;;) {
+        // ---- next sample of this lane: iteration (chunk - first chunk of its tile) * 64 + lane
+        uint32_t tile = 0;
+        uint64_t iteration = 0;
+        TileArea area{};
+        bool have = false;
+        while (chunk < L.chunk_end) {
+            const uint32_t row_chunks = (L.tiles_x - 1) * L.chunks_interior + L.chunks_right;
+            const uint32_t full_rows = L.tiles_y - 1;
+            uint32_t ty, r, per_tile;
+            if (chunk < full_rows * row_chunks) {
+                ty = chunk / row_chunks;
+                r = chunk - ty * row_chunks;
+                per_tile = L.chunks_interior;
+            } else {
+                ty = full_rows;
+                r = chunk - full_rows * row_chunks;
+                per_tile = L.chunks_bottom;
+            }
+            uint32_t tx = min(r / per_tile, L.tiles_x - 1);
+            uint32_t within = r - tx * per_tile;
+            tile = ty * L.tiles_x + tx;
+            uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
+            uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
+            uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
+            iteration = (uint64_t)within * 64u + lane;
+            chunk += total_waves;
+            if (iteration < iterations) {
+                area = to_view_area(sx, sy, w, h, L.film.width, L.film.height);
+                have = true;
+                break;
+            }
+        }
+        if (!have) break;
+
+        Rng rng = rng_seed(L.seed, tile, iteration);
+        if (COUNT) cnt.samples++;
+
+        // Tile::sample_point, renderer/algorithm.rs:113-119 (unfused: decides the pixel)
+        const float px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(rng)));
+        const float py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(rng)));
+
+        // Camera::ray_towards, cameras.rs:70-97
+        f3 ray_o, ray_d;
+        {
+            float focus_x = px / L.camera.view_plane * L.camera.focus_distance;
+            float focus_y = py / L.camera.view_plane * L.camera.focus_distance;
+            f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
+            f3 origin = mk(0, 0, 0), direction = target;
+            if (L.camera.aperture > 0.0f) {
+                float sqrt_r = sqrtf(L.camera.aperture * rng_f32(rng));
+                float psi = PI_F * 2.0f * rng_f32(rng);
+                origin = mk(sqrt_r * cos32(psi), sqrt_r * sin32(psi), 0.0f);
+                direction = target - origin;
+            }
+            ray_o = transform_point(L.camera.cam_to_world, origin);
+            ray_d = transform_vector(L.camera.cam_to_world, normalize(direction));
+        }
+
+        // Film::sample_many_wavelengths (film.rs:68-83) + hero pick by swap_remove (simple.rs:105-107)
+        float main_wl, main_bright = 0.0f, main_refl = 1.0f;
+        {
+            float step_size = L.film.wl_width / (float)SS;
+            float from = L.film.wl_start;
+            for (uint32_t k = 0; k < SS; ++k) {
+                float to = __fadd_rn(from, step_size);
+                spec.wl(k) = rng_range_f32(rng, from, to);
+                from = to;
+            }
+            uint32_t hero = rng_range_usize(rng, SS);
+            main_wl = spec.wl(hero);
+            spec.wl(hero) = spec.wl(SS - 1);
+            for (uint32_t k = 0; k + 1 < SS; ++k) {
+                spec.bright(k) = 0.0f;
+                spec.refl(k) = 1.0f;
+            }
+        }
+        const uint32_t n_add = SS - 1;
+        bool use_additional = true;
+
+        // tracer::trace, tracer.rs:208-345, with `contribute` (renderer/algorithm.rs:14-100) applied as each bounce is made
+        bool sample_light = true;
+        uint32_t light_sample_events = 0;
+        for (uint32_t bounce = 0; bounce < L.bounces; ++bounce) {
+            Hit hit;
+            if (COUNT) cnt.extension_rays++;
+            const bool found = traverse<COUNT, false>(S, ray_o, ray_d, 0.0f, hit, stack, cnt);
+            if (!found) {
+                // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
+                uint32_t color = S.sky_program;
+                if (sample_light) {
+                    for (uint32_t i = 0; i < S.num_lamps; ++i) {
+                        const DevLamp& l = S.lamps[i];
+                        if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
+                            color = l.color_program;
+                            break;
+                        }
+                    }
+                }
+                VmInput in{main_wl, -ray_d, ray_d};
+                main_bright += run_program(S, color, in) * 1.0f * main_refl;
+                if (use_additional)
+                    for (uint32_t k = 0; k < n_add; ++k) {
+                        in.wavelength = spec.wl(k);
+                        spec.bright(k) += run_program(S, color, in) * 1.0f * spec.refl(k);
+                    }
+                break;
+            }
+            if (COUNT) cnt.shaded_hits++;
+            f3 position, normal;
+            uint32_t material_id;
+            surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
+            const PyrMaterial material = S.materials[material_id];
+            const uint32_t pick = rng_choose(rng, material.num_components); // choose_component, materials/mod.rs:48-54
+            const PyrComponent comp = S.components[material.first_component + pick];
+            // get_probability, materials/mod.rs:238-248
+            float component_probability = comp.selection_compensation;
+            bool normal_dispersed = false;
+            if (comp.probability_program >= 0) {
+                VmInput pin{main_wl, normal, ray_d};
+                component_probability = run_program(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+                normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
+            }
+
+            if (comp.bsdf == PYR_BSDF_EMISSIVE) { // Scattering::Emitted, tracer.rs:303-318
+                if (sample_light) {
+                    use_additional = !normal_dispersed && use_additional;
+                    VmInput in{main_wl, normal, ray_d};
+                    main_bright += run_program(S, comp.color_program, in) * component_probability * main_refl;
+                    if (use_additional)
+                        for (uint32_t k = 0; k < n_add; ++k) {
+                            in.wavelength = spec.wl(k);
+                            spec.bright(k) += run_program(S, comp.color_program, in) * component_probability * spec.refl(k);
+                        }
+                }
+                break;
+            }
+
+            // SurfaceBsdfType::scatter, materials/mod.rs:344-359
+            f3 out_direction;
+            float scatter_probability = 1.0f;
+            bool dispersed = false, has_brdf = false;
+            if (comp.bsdf == PYR_BSDF_DIFFUSE) { // diffuse.rs:8-25
+                f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                out_direction = sample_hemisphere(rng, n);
+                has_brdf = true;
+            } else if (comp.bsdf == PYR_BSDF_MIRROR) { // mirror.rs:5-21
+                f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                float perp = dot(ray_d, n) * 2.0f;
+                out_direction = ray_d - n * perp;
+            } else { // refractive.rs:6-37
+                dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
+                float ior = comp.ior, env_ior = comp.env_ior;
+                if (dispersed) {
+                    float wl = main_wl * 0.001f;
+                    ior = comp.ior + comp.dispersion / (wl * wl);
+                    env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
+                }
+                refract(ior, env_ior, ray_d, normal, rng, out_direction, scatter_probability);
+            }
+
+            // contribute, non-emission bounce, first half (algorithm.rs:48-63): reflectance *= color * probability
+            const float bounce_probability = scatter_probability * component_probability; // tracer.rs:296
+            use_additional = !(dispersed || normal_dispersed) && use_additional;           // simple.rs:122-123, tracer.rs:290
+            {
+                VmInput in{main_wl, normal, ray_d};
+                main_refl *= run_program(S, comp.color_program, in) * bounce_probability;
+                if (use_additional)
+                    for (uint32_t k = 0; k < n_add; ++k) {
+                        in.wavelength = spec.wl(k);
+                        spec.refl(k) *= run_program(S, comp.color_program, in) * bounce_probability;
+                    }
+            }
+
+            // next-event estimation gate, tracer.rs:257-280
+            if (light_sample_events < 2) {
+                sample_light = !has_brdf || L.light_samples == 0;
+                if (has_brdf) {
+                    light_sample_events += 1;
+                    if (S.num_lamps > 0) { // trace_direct, tracer.rs:347-442
+                        const uint32_t lamp_index = rng_range_usize(rng, S.num_lamps); // pick_lamp, world.rs:301-305
+                        const DevLamp& lamp = S.lamps[lamp_index];
+                        const float lamp_probability = 1.0f / (float)S.num_lamps;
+                        const f3 nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                        const float probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                        for (uint32_t ls_i = 0; ls_i < L.light_samples; ++ls_i) {
+                            const LampSample ls = lamp_sample(lamp, rng, position);
+                            const float cos_out = fmaxf(dot(nff, ls.direction), 0.0f);
+                            if (!(cos_out > 0.0f)) continue;
+                            if (COUNT) cnt.shadow_rays++;
+                            const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
+                            Hit shadow_hit;
+#ifdef PYR_SHADOW_CLOSEST
+                            {
+                                bool has = traverse<COUNT, false>(S, position, ls.direction, limit, shadow_hit, stack, cnt);
+                                bool blocked = has && !(ls.sq_distance >= 0.0f && shadow_hit.t * shadow_hit.t >= ls.sq_distance - DIST_EPSILON);
+                                if (blocked) continue;
+                            }
+#else
+                            if (traverse<COUNT, true>(S, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
+#endif
+                            uint32_t l_color = ls.color;
+                            float material_probability = 1.0f;
+                            bool l_dispersed = false;
+                            f3 target_normal = -ls.direction;
+                            if (ls.physical) {
+                                const PyrMaterial lm = S.materials[ls.material];
+                                const uint32_t e_pick = rng_choose(rng, lm.num_emissive); // choose_emissive, materials/mod.rs:56-62
+                                const PyrComponent ec = S.components[lm.first_emissive + e_pick];
+                                material_probability = ec.selection_compensation;
+                                if (ec.probability_program >= 0) {
+                                    VmInput pin{main_wl, ls.normal, ls.direction};
+                                    material_probability = run_program(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                                    l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
+                                }
+                                l_color = ec.color_program;
+                                target_normal = ls.normal;
+                            }
+                            const float scale = ls.weight * probability * (2.0f * fabsf(dot(ls.direction, nff))); // lambertian, diffuse.rs:27-29
+                            const float l_probability = scale * material_probability;
+                            // contribute, direct light (algorithm.rs:65-90)
+                            VmInput in{main_wl, target_normal, ls.direction};
+                            main_bright += run_program(S, l_color, in) * l_probability * main_refl;
+                            if (use_additional && !l_dispersed)
+                                for (uint32_t k = 0; k < n_add; ++k) {
+                                    in.wavelength = spec.wl(k);
+                                    spec.bright(k) += run_program(S, l_color, in) * l_probability * spec.refl(k);
+                                }
+                        }
+                    }
+                }
+            } else {
+                sample_light = true;
+            }
+
+            // contribute, second half (algorithm.rs:92-98): reflectance *= brdf (2|n.out| for diffuse, tracer.rs:175-183)
+            if (has_brdf) {
+                const float brdf = 2.0f * fabsf(dot(out_direction, normal));
+                main_refl *= brdf;
+                if (use_additional)
+                    for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+            }
+            ray_o = position;
+            ray_d = out_direction;
+        }
+
+        // simple.rs:133-139
+        film_expose<COUNT>(L, px, py, main_wl, main_bright, cnt);
+        if (use_additional)
+            for (uint32_t k = 0; k < n_add; ++k) film_expose<COUNT>(L, px, py, spec.wl(k), spec.bright(k), cnt);
+    }
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
+    return (size_t)(3 * launch.spectrum_samples + scene.stack_depth) * BLOCK * sizeof(float);
+}
+
+int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus) {
+    const size_t lds = render_lds_bytes(scene, launch);
+    if (lds > 160 * 1024) {
+        g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
+        return PYR_ERR_UNSUPPORTED;
+    }
+    auto kernel = with_counters ? render_kernel<true> : render_kernel<false>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    int blocks_per_cu = 0;
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds);
+    if (err != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
+    const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
+    if (chunks == 0) return PYR_OK;
+    uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
+    uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
+    if (grid > blocks_needed) grid = blocks_needed;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("render kernel launch: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    return PYR_OK;
+}
+
+int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream) {
+    if (launch.n == 0) return PYR_OK;
+    const size_t lds = (size_t)scene.stack_depth * BLOCK * sizeof(int);
+    auto kernel = with_counters ? intersect_kernel<true> : intersect_kernel<false>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    uint32_t grid = (launch.n + BLOCK - 1) / BLOCK;
+    if (grid > 256 * 8) grid = 256 * 8;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("intersect kernel launch: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    return PYR_OK;
+}
+
+} // namespace pyr
