@@ -107,10 +107,18 @@ class Renderer:
             p.film_row_begin, p.film_row_count = int(film_rows[0]), int(film_rows[1])
         return p
 
-    def render(self, film: Film, camera: Camera, world: World, on_status=None, device=0, counters=False):
-        """Blocking render into a host Film (adds to it). Returns the PyrCounters dict when counters=True."""
-        params = self.params(abi.PYR_FLAG_COUNTERS if counters else 0)
+    def render(self, film: Film, camera: Camera, world: World, on_status=None, device=0, counters=False, tile_range=None, film_rows=None,
+               window=None):
+        """Blocking render into a host Film (adds to it). Returns the PyrCounters dict when counters=True.
+        `tile_range` restricts the call to raster tiles [a, b); with film_rows=(first_row, rows) the exposures go to `window`,
+        a float32 [rows, width, bins, 2] array covering only those rows of the image `film` describes."""
+        params = self.params(abi.PYR_FLAG_COUNTERS if counters else 0, tile_range, film_rows)
         desc = film.desc()
+        if window is not None:
+            assert window.flags["C_CONTIGUOUS"] and window.dtype == np.float32 and window.shape == (film_rows[1], film.width, film.bins, 2)
+            check(lib().pyr_render_simple(world.scene(device), C.byref(camera.c), C.byref(desc), C.byref(params), window.ctypes.data,
+                                          C.cast(None, abi.PyrProgressFn), None))
+            return self.counters(world, device) if counters else None
         if on_status is not None:
             cb = abi.PyrProgressFn(lambda user, percent, message: on_status(int(percent), message.decode()))
         else:

@@ -226,3 +226,75 @@ CONFIGS = {
     "C3": c3_mesh_in_box,
     "C5": lambda **kw: c3_mesh_in_box(glass=True, bounces=20, **{"pixel_samples": 4096, **kw}),
 }
+
+
+# ------------------------------------------------------------------------------------------------
+# Small scenes that follow the reference's other example projects; used by the parity tests to reach the
+# code paths C1-C5 do not (interpreted programs, curve spectra, mirror / dispersive glass, thin lens, point and
+# directional lamps, planes, sky).
+# ------------------------------------------------------------------------------------------------
+def spheres_example(width=128, height=64, pixel_samples=16):
+    """pyrite/test/spheres/spheres.lua:1-69 (simple renderer, D65 ball lamp, fresnel mirror/diffuse mix, curve spectra)."""
+    from .project import fresnel, light_source, mix
+
+    ball = shape.sphere(radius=1.5, position=vector(0, 1.4, 10), material=None)
+    green = spectrum(format="curve", points=[(400, 0), (450, 0.3), (500, 0), (550, 1), (600, 0)])
+    red = spectrum(format="curve", points=[(580, 0), (600, 1), (610, 1), (650, 0)])
+    objects = [
+        shape.sphere(radius=50.0, position=vector(0, -50, 10), material={"surface": material.diffuse(color=1)}),
+        ball.with_(position=vector(0, 1.5, 10), material={"surface": material.emissive(color=light_source.d65 * 3)}),
+        ball.with_(position=vector(-3, 1.4, 10),
+                   material={"surface": mix(material.mirror(color=1), material.diffuse(color=green), fresnel(1.5))}),
+        ball.with_(position=vector(3, 1.4, 10), material={"surface": material.diffuse(color=red)}),
+    ]
+    return {
+        "image": {"width": width, "height": height},
+        "camera": camera.perspective(fov=53, transform=transform.look_at(**{"from": vector(0, 1, 0), "to": vector(0, 1, 1)})),
+        "renderer": renderer.simple(pixel_samples=pixel_samples, spectrum_samples=10, spectrum_bins=50, tile_size=32, light_samples=4),
+        "world": {"objects": objects},
+    }
+
+
+def diamonds_example(width=128, height=75, pixel_samples=8, bounces=32):
+    """pyrite/test/diamonds/diamonds.lua:1-60 (dispersive glass mesh, plexi mirror with a fresnel mix colour, two quad
+    lamps, thin lens, spectrum_samples = 1). `bounces` is 256 in the project file; tests use fewer."""
+    from .project import fresnel, light_source, mix
+
+    diamond = {"surface": material.refractive(ior=2.37782, dispersion=0.01371, color=1)}
+    plexi = {"surface": material.mirror(color=mix(0, 0.2, fresnel(1.1)))}
+    mesh = shape.mesh(file=os.path.join(DATA_DIR, "diamonds.obj"), materials={
+        "diamonds": diamond,
+        "light_left": {"surface": material.emissive(color=light_source.d65)},
+        "light_right": {"surface": material.emissive(color=light_source.d65 * 2)},
+        "bottom": plexi,
+    })
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": renderer.simple(pixel_samples=pixel_samples, spectrum_samples=1, spectrum_bins=50, tile_size=32, bounces=bounces),
+        "camera": camera.perspective(fov=12.5, focus_distance=11.08, aperture=0.02,
+                                     transform=transform.look_at(**{"from": vector(-6.55068, -8.55076, 4.0), "to": vector(0.1, 0, 0.1),
+                                                                    "up": vector(z=1)})),
+        "world": {"objects": [mesh]},
+    }
+
+
+def lamps_example(width=96, height=64, pixel_samples=16):
+    """Point lamp + directional lamp + sky over a plane floor with a glass sphere (constant ior: companions survive),
+    a blackbody-coloured diffuse sphere and an rgb() coloured sphere: the lamp kinds and opcodes no other scene reaches
+    (lamp.rs:24-52, tracer.rs:444-459, shapes/mod.rs:441-452, Blackbody / RgbSpectrumValue)."""
+    from .project import blackbody, light, light_source, rgb
+
+    objects = [
+        shape.plane(origin=vector(0, 0, 0), normal=vector(z=1), material={"surface": material.diffuse(color=0.5)}),
+        shape.sphere(position=vector(-1.2, 0, 1), radius=1.0, material={"surface": material.refractive(ior=1.5, color=1)}),
+        shape.sphere(position=vector(1.2, 0.5, 0.7), radius=0.7, material={"surface": material.diffuse(color=blackbody(3000) * 2e-13)}),
+        shape.sphere(position=vector(0.2, -1.6, 0.5), radius=0.5, material={"surface": material.diffuse(color=rgb(0.8, 0.3, 0.1))}),
+        light.point(position=vector(3, -3, 5), color=light_source.d65 * 40),
+        light.directional(direction=vector(-0.3, 0.2, 0.933), width=0.98, color=light_source.a * 2),
+    ]
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": renderer.simple(pixel_samples=pixel_samples, light_samples=2, bounces=6, tile_size=16),
+        "camera": camera.perspective(fov=45, transform=transform.look_at(**{"from": vector(0, -7, 2.5), "to": vector(0, 0, 0.8), "up": vector(z=1)})),
+        "world": {"sky": light_source.d65 * 0.2, "objects": objects},
+    }

@@ -94,15 +94,18 @@ class OracleScene:
         self.handle = C.c_void_p()
         _check(lib().oracle_scene_create(C.byref(world.desc), C.byref(self.handle)))
 
-    def render(self, renderer, camera, film, threads=1, tile_range=None, film_rows=None):
+    def render(self, renderer, camera, film, threads=1, tile_range=None, film_rows=None, window=None):
+        """Adds one render into `film.grains`, or -- with film_rows=(first_row, rows) -- into `window`, a float32
+        [rows, width, bins, 2] array covering only those rows of the image `film` describes."""
         params = renderer.params(0, tile_range, film_rows)
         desc = film.desc()
         counters = abi.PyrCounters()
-        grains = np.ascontiguousarray(film.grains)
-        _check(lib().oracle_render_simple(self.handle, C.byref(camera.c), C.byref(desc), C.byref(params), grains.ctypes.data, threads,
+        target = film.grains if window is None else window
+        assert target.flags["C_CONTIGUOUS"] and target.dtype == np.float32
+        if film_rows is not None:
+            assert target.shape == (film_rows[1], film.width, film.bins, 2)
+        _check(lib().oracle_render_simple(self.handle, C.byref(camera.c), C.byref(desc), C.byref(params), target.ctypes.data, threads,
                                           C.byref(counters)))
-        if grains is not film.grains:
-            film.grains[...] = grains
         return counters.as_dict()
 
     def intersect(self, rays):

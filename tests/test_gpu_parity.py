@@ -1,0 +1,206 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on identical seeds -- run with `-m gpu` on an MI355X.
+
+Stated tolerance (north_star: "within a stated per-pixel spectral L2 tolerance"): with s = acc / weight per bin,
+    relL2(pixel) = ||s_gpu - s_cpu||_2 / (||s_cpu||_2 + 1e-6)
+must be <= 1e-5 for at least 99.9 % of the pixels, and the film WEIGHTS (integer sample counts per bin) must be identical.
+The kernels and the oracle perform the same f32 operations in the same order (no FMA contraction, transcendentals rounded
+once from f64, the same RNG streams), so paths agree bit for bit and only the order of the float atomics differs; the
+0.1 % allowance covers the ~1e-8-per-call double-rounding cases of the transcendentals. Integer / index results
+(hit shapes, counters, weights) must be exact."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pyrite_amd import scenes
+from pyrite_amd.project import renderer
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL, FRACTION = 1e-5, 0.999
+
+
+def rel_l2(gpu_film, cpu_film):
+    a, b = gpu_film.develop(), cpu_film.develop()
+    return (np.sqrt(((a - b) ** 2).sum(-1)) / (np.sqrt((b ** 2).sum(-1)) + 1e-6)).reshape(-1)
+
+
+def assert_parity(gpu_film, cpu_film):
+    assert np.array_equal(gpu_film.grains[..., 1], cpu_film.grains[..., 1]), "film weights differ"
+    e = rel_l2(gpu_film, cpu_film)
+    assert (e <= TOL).mean() >= FRACTION, "relL2: median %.3g p99 %.3g max %.3g" % (np.median(e), np.percentile(e, 99), e.max())
+    assert not np.isnan(gpu_film.grains).any()
+
+
+def render_both(project, seed, gpu_lib, threads=8):
+    world, cam, r, gfilm = scenes.build(project, seed=seed)
+    cfilm = r.new_film(gfilm.width, gfilm.height)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=threads)
+    gcount = r.render(gfilm, cam, world, counters=True)
+    return gfilm, cfilm, gcount, ccount
+
+
+def random_rays(n, seed, lo, hi):
+    rng = np.random.RandomState(seed)
+    o = rng.uniform(lo, hi, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def assert_same_hits(ohits, ghits):
+    """Distances are bit-exact except where two primitives are hit at (numerically almost) the same distance: both sides
+    keep the smallest distance they SEE, but a zero-thickness box whose entry distance rounds an ulp above the current
+    closest hit is culled (bvh.rs:213), so near-ties can resolve to either primitive depending on the visiting order --
+    a property of the reference's own traversal. Allowed: <= 0.2 % of the rays, and then only a few-ulp difference."""
+    od, gd = ohits["distance"], ghits["distance"]
+    exact = od == gd
+    assert exact.mean() >= 0.998, "distance mismatches: %d of %d" % ((~exact).sum(), len(od))
+    assert np.allclose(od[~exact], gd[~exact], rtol=2e-6, atol=0)
+    same = ohits["shape"] == ghits["shape"]
+    assert (~same).mean() < 0.01  # different shape only as a tie (coincident / edge-sharing primitives)
+    assert np.allclose(od[~same], gd[~same], rtol=2e-6, atol=0)
+    both = same & exact
+    assert np.array_equal(ohits["u"][both], ghits["u"][both]) and np.array_equal(ohits["v"][both], ghits["v"][both])
+
+
+CASES = {
+    "c1_spheres": lambda: scenes.c1_spheres(64, 64, 16),
+    "c2_cornell": lambda: scenes.c2_cornell(64, 64, 16),
+    "spheres_example": lambda: scenes.spheres_example(96, 48, 16),
+    "diamonds_example": lambda: scenes.diamonds_example(64, 40, 8, bounces=32),
+    "lamps_example": lambda: scenes.lamps_example(72, 48, 16),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_render_matches_the_oracle(name, gpu_lib):
+    gfilm, cfilm, gcount, ccount = render_both(CASES[name](), 5, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    # path-level counters are exact; box / primitive test counts differ because the two sides walk different trees
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+
+
+def test_ragged_image_and_odd_parameters(gpu_lib):
+    project = scenes.c2_cornell(50, 37, 3)  # tiles of 16: ragged right column and bottom row
+    project["renderer"] = renderer.simple(pixel_samples=3, tile_size=16, spectrum_samples=7, light_samples=1, bounces=3)
+    gfilm, cfilm, gcount, ccount = render_both(project, 9, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    assert gcount["samples"] == 50 * 37 * 3 == ccount["samples"]
+
+
+def test_vertical_image_single_wavelength_and_no_light_samples(gpu_lib):
+    project = scenes.c1_spheres(24, 40, 4)
+    project["renderer"] = renderer.simple(pixel_samples=4, tile_size=32, spectrum_samples=1, light_samples=0, bounces=5)
+    gfilm, cfilm, _, _ = render_both(project, 2, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    assert gfilm.total_weight() == 24 * 40 * 4
+
+
+def test_empty_work_is_a_no_op(gpu_lib):
+    world, cam, r, film = scenes.build(scenes.c2_cornell(16, 16, 0), seed=1)  # zero samples per pixel
+    r.render(film, cam, world)
+    assert film.grains.sum() == 0
+    r.pixel_samples = 2
+    r.render(film, cam, world, tile_range=(1, 1))  # empty tile range (tile_end == 0 would mean "all tiles")
+    assert film.grains.sum() == 0
+    hits, ms, _ = world.intersect(np.zeros((0, 6), dtype=np.float32))
+    assert len(hits) == 0
+
+
+@pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "lamps_example"])
+def test_closest_hit_matches_the_oracle_exactly(name, gpu_lib):
+    world, cam, r, film = scenes.build(CASES[name](), seed=1)
+    rays = random_rays(100000, 3, [-6, -1, 0.05], [0.5, 6, 5.4])
+    ohits, _ = oracle.OracleScene(world).intersect(rays)
+    ghits, ms, counters = world.intersect(rays, want_counters=True)
+    assert_same_hits(ohits, ghits)
+    assert counters["box_tests"] > 0
+
+
+def test_closest_hit_on_a_dense_mesh(gpu_lib):
+    from pyrite_amd.compiler import FlatScene
+    from pyrite_amd.project import material
+    from pyrite_amd.renderer import World
+
+    flat = FlatScene()
+    flat.sky_program = flat.compile(0.0)
+    mat, _ = flat.add_material({"surface": material.diffuse(color=0.8)})
+    pos, nrm = scenes.torus_knot_mesh(segments=96, sides=48, fit_min=(-4, -4, -4), fit_max=(4, 4, 4))
+    flat.add_triangles(pos, nrm, mat)
+    world = World(flat)
+    info = world.bvh_info()
+    assert info["num_primitives"] == 96 * 48 * 2 and info["max_depth"] <= 40
+    rays = random_rays(60000, 8, [-5, -5, -5], [5, 5, 5])
+    ohits, _ = oracle.OracleScene(world).intersect(rays)
+    ghits, _, _ = world.intersect(rays)
+    assert_same_hits(ohits, ghits)
+    assert (ohits["shape"] != 0xFFFFFFFF).mean() > 0.1
+
+
+@pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example"])
+def test_gpu_reproduces_the_committed_golden_films(name, gpu_lib):
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    data = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(data["meta"]))
+    world, cam, r, film = scenes.build(mg.build_case(name), seed=meta["seed"])
+    r.render(film, cam, world)
+    golden = r.new_film(film.width, film.height)
+    golden.grains[...] = data["grains"]
+    assert_parity(film, golden)
+    ghits, _, _ = world.intersect(data["rays"])
+    golden_hits = np.zeros(len(ghits), dtype=ghits.dtype)
+    golden_hits["distance"], golden_hits["shape"], golden_hits["u"], golden_hits["v"] = data["hit_distance"], data["hit_shape"], data["hit_u"], data["hit_v"]
+    assert_same_hits(golden_hits, ghits)
+
+
+def test_tile_ranges_windows_and_progress(gpu_lib):
+    world, cam, r, film = scenes.build(scenes.c1_spheres(48, 40, 2), seed=4)
+    r.tile_size = 16
+    seen = []
+    r.render(film, cam, world, on_status=lambda percent, message: seen.append((percent, message)))
+    assert seen[0] == (0, "Rendering") and seen[-1][0] == 100  # simple.rs:30-34, :49-54
+    parts = r.new_film(48, 40)
+    for lo, hi in ((0, 4), (4, 5), (5, 9)):
+        r.render(parts, cam, world, tile_range=(lo, hi))
+    assert np.array_equal(film.grains[..., 1], parts.grains[..., 1])
+    assert np.allclose(film.grains, parts.grains, rtol=1e-5)
+    window = np.zeros((18, 48, film.bins, 2), dtype=np.float32)  # tile row 1 = pixel rows 16..31, plus halo rows 15 and 32
+    r.render(film, cam, world, tile_range=(3, 6), film_rows=(15, 18), window=window)
+    only = r.new_film(48, 40)
+    r.render(only, cam, world, tile_range=(3, 6))
+    assert np.allclose(window, only.grains[15:33], rtol=1e-6)
+    assert only.grains[:15].sum() == 0 and only.grains[33:].sum() == 0
+
+
+def test_full_size_c2_properties(gpu_lib):
+    """BASELINE.json configs[1] at its full image size (1024 x 1024; 2 of the 256 spp) through size-independent properties:
+    every sample exposes exactly S wavelengths (weights sum to samples * S), weights are whole numbers, a second render
+    adds linearly, and a band of tiles equals the same band of the whole image."""
+    world, cam, r, film = scenes.build(scenes.c2_cornell(1024, 1024, 2), seed=11)
+    counters = r.render(film, cam, world, counters=True)
+    assert counters["samples"] == 1024 * 1024 * 2 and counters["exposures"] == counters["samples"] * 10
+    assert film.grains[..., 1].sum(dtype=np.float64) == counters["exposures"]
+    assert np.array_equal(film.grains[..., 1], np.round(film.grains[..., 1]))
+    assert np.isfinite(film.grains).all() and (film.grains[..., 0] >= 0).all()
+    once = film.grains.copy()
+    r.render(film, cam, world)  # same seed again: the film is a pure accumulator
+    assert np.array_equal(film.grains[..., 1], 2 * once[..., 1])
+    assert np.allclose(film.grains[..., 0], 2 * once[..., 0], rtol=1e-5)
+    band = r.new_film(1024, 1024)
+    r.render(band, cam, world, tile_range=(32 * 10, 32 * 12))  # tile rows 10 and 11
+    rows = slice(10 * 32 + 1, 12 * 32 - 1)  # interior rows: no other tile row can leak into them
+    assert np.array_equal(band.grains[rows][..., 1], once[rows][..., 1])
+    assert np.allclose(band.grains[rows], once[rows], rtol=1e-5)
+    # the oracle on a few tiles of the full-size image (tile-level parity at BASELINE size)
+    cpu = r.new_film(1024, 1024)
+    oracle.OracleScene(world).render(r, cam, cpu, threads=8, tile_range=(32 * 16 + 14, 32 * 16 + 18))
+    gpu = r.new_film(1024, 1024)
+    r.render(gpu, cam, world, tile_range=(32 * 16 + 14, 32 * 16 + 18))
+    assert_parity(gpu, cpu)
