@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric (Msamples/s of the camera-to-light renderer) on BASELINE.json's configs[1].
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A *step* is one complete pass of the hot path over the workload: the whole C2 image (1024 x 1024, 256 spp = 268.4 M
+samples) rendered into a film that is already resident in HBM (scene uploaded and film allocated before the timed
+region). With N > 1 the image's tiles are split into N contiguous raster ranges (strong scaling: the image is fixed), every
+rank renders its range into its own film window and ONE RCCL gather brings the windows to rank 0; the gather is inside the
+step. Timing: barrier + synchronize on both sides of exactly K steps, max over ranks, rank 0 prints one JSON line.
+
+Extra objects on the line:
+  roofline      algorithmic bytes (32 B per box test, 36 B per triangle test, 16 B per sphere / plane
+                test, 52 B per shaded hit, 16 B per film exposure; counts from an instrumented run of the same launch,
+                outside the timed region) over the kernel's average launch duration measured with HIP events on the launch
+                stream, against the 8 TB/s HBM3E peak. `traffic` (PMC HBM bytes) comes from the rocprofv3 --pmc passes
+                whose summary is committed under profiles/ (null when no summary for this workload is present).
+  cpu_baseline  the CPU oracle (oracle/liboracle.so, a port of the reference's algorithm -- the Rust reference cannot be
+                built here) timed on this host's cores, rank 0, N = 1 only, on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene builder name, width, height, spp)
+    "C2": ("c2_cornell", 1024, 1024, 256),
+    "C1": ("c1_spheres", 256, 256, 64),
+    "C3": ("c3_mesh_in_box", 1920, 1080, 1024),
+}
+BYTES = dict(box_tests=32, triangle_tests=36, sphere_tests=16, plane_tests=16, shaded_hits=52, exposures=16)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(counters):
+    return sum(BYTES[k] * counters[k] for k in BYTES)
+
+
+def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
+    """Time the oracle on the same scene and image with fewer samples per pixel (the loop is linear in spp, simple.rs:73)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import copy
+
+    import oracle
+
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sc = oracle.OracleScene(world)
+    r = copy.copy(renderer)
+    # calibrate on a few central tiles, then size the sample for ~target_seconds
+    r.pixel_samples = 1
+    tiles = renderer.num_tiles(width, height)
+    probe = (tiles // 2, min(tiles, tiles // 2 + 4 * threads))
+    film = renderer.new_film(width, height)
+    t0 = time.perf_counter()
+    c = sc.render(r, cam, film, threads=threads, tile_range=probe)
+    rate = c["samples"] / max(time.perf_counter() - t0, 1e-6)
+    spp = int(max(1, min(renderer.pixel_samples, round(rate * target_seconds / (width * height)))))
+    r.pixel_samples = spp
+    film = renderer.new_film(width, height)
+    t0 = time.perf_counter()
+    c = sc.render(r, cam, film, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(c["samples"] / dt / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "same scene and %dx%d image at %d spp of %d (all tiles), %.1f s of CPU work" % (width, height, spp, renderer.pixel_samples, dt),
+    }
+
+
+def load_traffic(workload):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            table = json.load(f)
+        entry = table.get(workload)
+        if entry:
+            return entry.get("hbm_bytes_per_launch")
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (development only: the line is then marked reduced)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from pyrite_amd import abi, scenes
+    from pyrite_amd import distributed as pdist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE is 1)" % args.gpus)
+        sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world_size))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    builder, width, height, spp = WORKLOADS[args.workload]
+    reduced = args.spp is not None and args.spp != spp
+    spp = args.spp or spp
+    project = getattr(scenes, builder)(width=width, height=height, pixel_samples=spp)
+    world, cam, renderer, _ = scenes.build(project, seed=args.seed)
+    world.scene(local_rank)  # BVH build + upload, outside the timed region
+    bins = renderer.spectrum_bins
+    film_desc = abi.PyrFilmDesc(width, height, bins, renderer.spectrum_span[0], renderer.spectrum_span[1] - renderer.spectrum_span[0])
+    stream = torch.cuda.current_stream(device)
+
+    def render_window(tile_range, rows, window, flags=0):
+        renderer.render_device(window.data_ptr(), film_desc, cam, world, stream=stream.cuda_stream, device=local_rank, flags=flags,
+                               tile_range=tile_range, film_rows=rows)
+
+    def step():
+        return pdist.render_sharded(render_window, width, height, bins, renderer.tile_size, device)
+
+    def fence():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    start_evt, stop_evt = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    start_evt.record(stream)
+    film = None
+    for _ in range(args.steps):
+        film = step()
+    stop_evt.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    samples = width * height * spp
+    value = samples / (ms_per_step * 1e-3) / 1e6
+
+    line = None
+    if rank == 0:
+        # sanity: every sample exposed spectrum_samples wavelengths into the gathered film
+        total_weight = float(film[..., 1].sum(dtype=torch.float64).item()) if film is not None else 0.0
+        expected_weight = float(samples) * renderer.spectrum_samples
+        line = {
+            "metric": "Msamples/sec",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s, %dx%d, %d spp%s" % (args.workload, builder, width, height, spp, " (REDUCED spp: development run)" if reduced else ""),
+                "bounces": renderer.bounces, "light_samples": renderer.light_samples, "spectrum_samples": renderer.spectrum_samples,
+                "spectrum_bins": bins, "tile_size": renderer.tile_size, "triangles": len(world.flat.tri_material), "spheres": len(world.flat.spheres),
+                "parallelism": "tiles sharded over %d GPU(s), one film gather" % world_size,
+                "film_weight_check": "ok" if abs(total_weight - expected_weight) < 0.5 else "MISMATCH %.0f vs %.0f" % (total_weight, expected_weight),
+            },
+        }
+    del film
+
+    if world_size == 1:
+        # kernel duration from HIP events on the launch stream (one launch per step at N = 1)
+        kernel_ms = start_evt.elapsed_time(stop_evt) / max(args.steps, 1)
+        # algorithmic bytes per launch: instrumented run of the same launch, outside the timed region
+        window = torch.zeros((height, width, bins, 2), dtype=torch.float32, device=device)
+        render_window((0, 0), (0, height), window, flags=abi.PYR_FLAG_COUNTERS)
+        torch.cuda.synchronize(device)
+        counters = renderer.counters(world, local_rank)
+        del window
+        traversal = 32 * counters["box_tests"] + 36 * counters["triangle_tests"] + 16 * (counters["sphere_tests"] + counters["plane_tests"])
+        total = algorithmic_bytes(counters)
+        achieved = total / (kernel_ms * 1e-3) / 1e9
+        line["roofline"] = {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": load_traffic(args.workload),
+            "kernel": "render_kernel<false>",
+            "kernel_ms": round(kernel_ms, 3),
+            "algorithmic_bytes_per_launch": int(total),
+            "traversal_bytes_per_launch": int(traversal),
+            "traversal_frac": round(traversal / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "counters": counters,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(world, cam, renderer, width, height)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

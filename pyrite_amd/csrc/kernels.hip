@@ -11,6 +11,7 @@
 // children's boxes), leaf primitives as 3 x dwordx4. Film exposure is two no-return global_atomic_add_f32 per exposure.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 
@@ -26,6 +27,7 @@ const char* kernels_last_error() { return g_kernel_error.c_str(); }
 #define DEV __device__ __forceinline__
 
 constexpr int BLOCK = 256;
+constexpr bool kRefillPerBounce = false;
 constexpr float DIST_EPSILON = 0.0001f; // math.rs:4
 constexpr float PI_F = 3.14159265358979323846f;
 #define PYR_INF __builtin_huge_valf()
@@ -584,34 +586,6 @@ DEV f3 transform_vector(const float* m, f3 v) {
 // Rust `as usize`: saturating, NaN -> 0 (values here are far below 2^32).
 DEV uint32_t f32_as_index(float f) { return f > 0.0f ? (f >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)f) : 0u; }
 
-// Film::expose (film.rs:89-95): wavelength_to_grain (:85-87), AspectRatio::to_pixel (:233-246), Grain::increment (:145-162)
-// as two no-return float atomics (the reference's 5-try CAS may drop samples under contention; atomics never do).
-template <bool COUNT>
-DEV void film_expose(const RenderLaunch& L, float px, float py, float wavelength, float brightness, Counters& cnt) {
-    const uint32_t width = L.film.width, height = L.film.height, bins = L.film.bins;
-    uint32_t grain = f32_as_index(__fmul_rn(__fsub_rn(wavelength, L.film.wl_start), L.grains_per_wavelength));
-    grain = grain < bins - 1 ? grain : bins - 1;
-    uint32_t x, y;
-    if (width >= height) {
-        float size = (float)width, ratio = __fdiv_rn((float)height, (float)width);
-        if (!(fabsf(py) <= ratio)) return;
-        x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, 1.0f)), 0.5f));
-        y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, ratio)), 0.5f));
-    } else {
-        float size = (float)height, ratio = __fdiv_rn((float)width, (float)height);
-        if (!(fabsf(px) <= ratio)) return;
-        x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, ratio)), 0.5f));
-        y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, 1.0f)), 0.5f));
-    }
-    if (x >= width || y >= height) return;
-    if (y < L.film_row_begin || y >= L.film_row_begin + L.film_row_count) return;
-    size_t index = ((size_t)x + (size_t)(y - L.film_row_begin) * width) * bins + grain;
-    float* g = reinterpret_cast<float*>(L.film_out + index);
-    atomicAdd(g, brightness); // value * weight with weight == 1 (simple.rs:95-98)
-    atomicAdd(g + 1, 1.0f);
-    if (COUNT) cnt.exposures++;
-}
-
 // ------------------------------------------------------------------------------------------------ the integrator
 // LDS: [3 * S][BLOCK] floats (wavelength, brightness, reflectance of the S-1 companions; slot S-1 is scratch during
 // sample generation) followed by [stack_depth][BLOCK] ints.
@@ -761,8 +735,42 @@ DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
     return ls;
 }
 
+// Pixel a view-plane position exposes to (AspectRatio::to_pixel, film.rs:233-246 + Film::get_pixel :51-54), as the index
+// of its first grain inside the film window, or -1 when the position maps outside the image / the window.
+DEV long long film_pixel_base(const RenderLaunch& L, float px, float py) {
+    const uint32_t width = L.film.width, height = L.film.height;
+    uint32_t x, y;
+    if (width >= height) {
+        float size = (float)width, ratio = __fdiv_rn((float)height, (float)width);
+        if (!(fabsf(py) <= ratio)) return -1;
+        x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, 1.0f)), 0.5f));
+        y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, ratio)), 0.5f));
+    } else {
+        float size = (float)height, ratio = __fdiv_rn((float)width, (float)height);
+        if (!(fabsf(px) <= ratio)) return -1;
+        x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, ratio)), 0.5f));
+        y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, 1.0f)), 0.5f));
+    }
+    if (x >= width || y >= height) return -1;
+    if (y < L.film_row_begin || y >= L.film_row_begin + L.film_row_count) return -1;
+    return (long long)(((size_t)x + (size_t)(y - L.film_row_begin) * width) * L.film.bins);
+}
+
+// Film::expose (film.rs:89-95) into a known pixel: wavelength_to_grain (:85-87) + Grain::increment (:145-162) as two
+// no-return float atomics (the reference's 5-try CAS may drop samples under contention; atomics never do).
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void render_kernel(DevScene S, RenderLaunch L) {
+DEV void expose_grain(const RenderLaunch& L, long long pixel_base, float wavelength, float brightness, Counters& cnt) {
+    if (pixel_base < 0) return;
+    uint32_t grain = f32_as_index(__fmul_rn(__fsub_rn(wavelength, L.film.wl_start), L.grains_per_wavelength));
+    grain = grain < L.film.bins - 1 ? grain : L.film.bins - 1;
+    float* g = reinterpret_cast<float*>(L.film_out + pixel_base + grain);
+    atomicAdd(g, brightness); // value * weight with weight == 1 (simple.rs:95-98)
+    atomicAdd(g + 1, 1.0f);
+    if (COUNT) cnt.exposures++;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
@@ -774,115 +782,131 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(DevScene S, RenderLaunch 
     const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t total_waves = gridDim.x * waves_per_block;
     uint32_t chunk = L.chunk_begin + wave; // this lane's next chunk; lanes advance independently
+    const uint32_t n_add = SS - 1;
+
+    // Per-path state. With kRefillPerBounce a loop iteration is ONE bounce and a lane whose path has ended starts its next
+    // sample at once; without it a wave walks its 64 paths bounce-synchronously. Measured on C2 (MI355X, 64 spp): refilling
+    // per bounce is 0.6x the speed -- it spreads the next-event-estimation section (4 shadow rays, run for the first two
+    // diffuse events only) over every iteration at ~40 % lane occupancy, where the synchronous walk runs it twice per
+    // batch at full occupancy and skips it afterwards. Kept for the record; the queue-based scheduler replaces both.
+    bool alive = false;
+    Rng rng{};
+    float px = 0.0f, py = 0.0f;
+    f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1);
+    float main_wl = 0.0f, main_bright = 0.0f, main_refl = 1.0f;
+    bool use_additional = true, sample_light = true;
+    uint32_t light_sample_events = 0, bounce = 0;
 
     for (;;) {
-        // ---- next sample of this lane: iteration (chunk - first chunk of its tile) * 64 + lane
-        uint32_t tile = 0;
-        uint64_t iteration = 0;
-        TileArea area{};
-        bool have = false;
-        while (chunk < L.chunk_end) {
-            const uint32_t row_chunks = (L.tiles_x - 1) * L.chunks_interior + L.chunks_right;
-            const uint32_t full_rows = L.tiles_y - 1;
-            uint32_t ty, r, per_tile;
-            if (chunk < full_rows * row_chunks) {
-                ty = chunk / row_chunks;
-                r = chunk - ty * row_chunks;
-                per_tile = L.chunks_interior;
-            } else {
-                ty = full_rows;
-                r = chunk - full_rows * row_chunks;
-                per_tile = L.chunks_bottom;
+        if (!alive) {
+            // ---- next sample of this lane: iteration (chunk - first chunk of its tile) * 64 + lane
+            uint32_t tile = 0;
+            uint64_t iteration = 0;
+            TileArea area{};
+            while (chunk < L.chunk_end) {
+                const uint32_t row_chunks = (L.tiles_x - 1) * L.chunks_interior + L.chunks_right;
+                const uint32_t full_rows = L.tiles_y - 1;
+                uint32_t ty, r, per_tile;
+                if (chunk < full_rows * row_chunks) {
+                    ty = chunk / row_chunks;
+                    r = chunk - ty * row_chunks;
+                    per_tile = L.chunks_interior;
+                } else {
+                    ty = full_rows;
+                    r = chunk - full_rows * row_chunks;
+                    per_tile = L.chunks_bottom;
+                }
+                uint32_t tx = min(r / per_tile, L.tiles_x - 1);
+                uint32_t within = r - tx * per_tile;
+                tile = ty * L.tiles_x + tx;
+                uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
+                uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
+                uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
+                iteration = (uint64_t)within * 64u + lane;
+                chunk += total_waves;
+                if (iteration < iterations) {
+                    area = to_view_area(sx, sy, w, h, L.film.width, L.film.height);
+                    alive = true;
+                    break;
+                }
             }
-            uint32_t tx = min(r / per_tile, L.tiles_x - 1);
-            uint32_t within = r - tx * per_tile;
-            tile = ty * L.tiles_x + tx;
-            uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
-            uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
-            uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
-            iteration = (uint64_t)within * 64u + lane;
-            chunk += total_waves;
-            if (iteration < iterations) {
-                area = to_view_area(sx, sy, w, h, L.film.width, L.film.height);
-                have = true;
-                break;
+            if (!alive) break; // no work left for this lane
+
+            rng = rng_seed(L.seed, tile, iteration);
+            if (COUNT) cnt.samples++;
+
+            // Tile::sample_point, renderer/algorithm.rs:113-119 (unfused: decides the pixel)
+            px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(rng)));
+            py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(rng)));
+
+            // Camera::ray_towards, cameras.rs:70-97
+            {
+                float focus_x = px / L.camera.view_plane * L.camera.focus_distance;
+                float focus_y = py / L.camera.view_plane * L.camera.focus_distance;
+                f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
+                f3 origin = mk(0, 0, 0), direction = target;
+                if (L.camera.aperture > 0.0f) {
+                    float sqrt_r = sqrtf(L.camera.aperture * rng_f32(rng));
+                    float psi = PI_F * 2.0f * rng_f32(rng);
+                    origin = mk(sqrt_r * cos32(psi), sqrt_r * sin32(psi), 0.0f);
+                    direction = target - origin;
+                }
+                ray_o = transform_point(L.camera.cam_to_world, origin);
+                ray_d = transform_vector(L.camera.cam_to_world, normalize(direction));
             }
+
+            // Film::sample_many_wavelengths (film.rs:68-83) + hero pick by swap_remove (simple.rs:105-107)
+            {
+                float step_size = L.film.wl_width / (float)SS;
+                float from = L.film.wl_start;
+                for (uint32_t k = 0; k < SS; ++k) {
+                    float to = __fadd_rn(from, step_size);
+                    spec.wl(k) = rng_range_f32(rng, from, to);
+                    from = to;
+                }
+                uint32_t hero = rng_range_usize(rng, SS);
+                main_wl = spec.wl(hero);
+                spec.wl(hero) = spec.wl(SS - 1);
+                for (uint32_t k = 0; k + 1 < SS; ++k) {
+                    spec.bright(k) = 0.0f;
+                    spec.refl(k) = 1.0f;
+                }
+            }
+            main_bright = 0.0f;
+            main_refl = 1.0f;
+            use_additional = true;
+            sample_light = true; // tracer.rs:218-219
+            light_sample_events = 0;
+            bounce = 0;
         }
-        if (!have) break;
 
-        Rng rng = rng_seed(L.seed, tile, iteration);
-        if (COUNT) cnt.samples++;
-
-        // Tile::sample_point, renderer/algorithm.rs:113-119 (unfused: decides the pixel)
-        const float px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(rng)));
-        const float py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(rng)));
-
-        // Camera::ray_towards, cameras.rs:70-97
-        f3 ray_o, ray_d;
-        {
-            float focus_x = px / L.camera.view_plane * L.camera.focus_distance;
-            float focus_y = py / L.camera.view_plane * L.camera.focus_distance;
-            f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
-            f3 origin = mk(0, 0, 0), direction = target;
-            if (L.camera.aperture > 0.0f) {
-                float sqrt_r = sqrtf(L.camera.aperture * rng_f32(rng));
-                float psi = PI_F * 2.0f * rng_f32(rng);
-                origin = mk(sqrt_r * cos32(psi), sqrt_r * sin32(psi), 0.0f);
-                direction = target - origin;
-            }
-            ray_o = transform_point(L.camera.cam_to_world, origin);
-            ray_d = transform_vector(L.camera.cam_to_world, normalize(direction));
-        }
-
-        // Film::sample_many_wavelengths (film.rs:68-83) + hero pick by swap_remove (simple.rs:105-107)
-        float main_wl, main_bright = 0.0f, main_refl = 1.0f;
-        {
-            float step_size = L.film.wl_width / (float)SS;
-            float from = L.film.wl_start;
-            for (uint32_t k = 0; k < SS; ++k) {
-                float to = __fadd_rn(from, step_size);
-                spec.wl(k) = rng_range_f32(rng, from, to);
-                from = to;
-            }
-            uint32_t hero = rng_range_usize(rng, SS);
-            main_wl = spec.wl(hero);
-            spec.wl(hero) = spec.wl(SS - 1);
-            for (uint32_t k = 0; k + 1 < SS; ++k) {
-                spec.bright(k) = 0.0f;
-                spec.refl(k) = 1.0f;
-            }
-        }
-        const uint32_t n_add = SS - 1;
-        bool use_additional = true;
-
-        // tracer::trace, tracer.rs:208-345, with `contribute` (renderer/algorithm.rs:14-100) applied as each bounce is made
-        bool sample_light = true;
-        uint32_t light_sample_events = 0;
-        for (uint32_t bounce = 0; bounce < L.bounces; ++bounce) {
-            Hit hit;
-            if (COUNT) cnt.extension_rays++;
-            const bool found = traverse<COUNT, false>(S, ray_o, ray_d, 0.0f, hit, stack, cnt);
-            if (!found) {
-                // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
-                uint32_t color = S.sky_program;
-                if (sample_light) {
-                    for (uint32_t i = 0; i < S.num_lamps; ++i) {
-                        const DevLamp& l = S.lamps[i];
-                        if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
-                            color = l.color_program;
-                            break;
-                        }
+        // ---- one bounce of tracer::trace (tracer.rs:221-344) with `contribute` (renderer/algorithm.rs:14-100) applied online
+        bool ended = false;
+        do {
+        Hit hit;
+        if (COUNT) cnt.extension_rays++;
+        const bool found = traverse<COUNT, false>(S, ray_o, ray_d, 0.0f, hit, stack, cnt);
+        if (!found) {
+            // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
+            uint32_t color = S.sky_program;
+            if (sample_light) {
+                for (uint32_t i = 0; i < S.num_lamps; ++i) {
+                    const DevLamp& l = S.lamps[i];
+                    if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
+                        color = l.color_program;
+                        break;
                     }
                 }
-                VmInput in{main_wl, -ray_d, ray_d};
-                main_bright += run_program(S, color, in) * 1.0f * main_refl;
-                if (use_additional)
-                    for (uint32_t k = 0; k < n_add; ++k) {
-                        in.wavelength = spec.wl(k);
-                        spec.bright(k) += run_program(S, color, in) * 1.0f * spec.refl(k);
-                    }
-                break;
             }
+            VmInput in{main_wl, -ray_d, ray_d};
+            main_bright += run_program(S, color, in) * 1.0f * main_refl;
+            if (use_additional)
+                for (uint32_t k = 0; k < n_add; ++k) {
+                    in.wavelength = spec.wl(k);
+                    spec.bright(k) += run_program(S, color, in) * 1.0f * spec.refl(k);
+                }
+            ended = true;
+        } else {
             if (COUNT) cnt.shaded_hits++;
             f3 position, normal;
             uint32_t material_id;
@@ -910,121 +934,119 @@ __global__ __launch_bounds__(BLOCK) void render_kernel(DevScene S, RenderLaunch 
                             spec.bright(k) += run_program(S, comp.color_program, in) * component_probability * spec.refl(k);
                         }
                 }
-                break;
-            }
-
-            // SurfaceBsdfType::scatter, materials/mod.rs:344-359
-            f3 out_direction;
-            float scatter_probability = 1.0f;
-            bool dispersed = false, has_brdf = false;
-            if (comp.bsdf == PYR_BSDF_DIFFUSE) { // diffuse.rs:8-25
-                f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                out_direction = sample_hemisphere(rng, n);
-                has_brdf = true;
-            } else if (comp.bsdf == PYR_BSDF_MIRROR) { // mirror.rs:5-21
-                f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                float perp = dot(ray_d, n) * 2.0f;
-                out_direction = ray_d - n * perp;
-            } else { // refractive.rs:6-37
-                dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
-                float ior = comp.ior, env_ior = comp.env_ior;
-                if (dispersed) {
-                    float wl = main_wl * 0.001f;
-                    ior = comp.ior + comp.dispersion / (wl * wl);
-                    env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
-                }
-                refract(ior, env_ior, ray_d, normal, rng, out_direction, scatter_probability);
-            }
-
-            // contribute, non-emission bounce, first half (algorithm.rs:48-63): reflectance *= color * probability
-            const float bounce_probability = scatter_probability * component_probability; // tracer.rs:296
-            use_additional = !(dispersed || normal_dispersed) && use_additional;           // simple.rs:122-123, tracer.rs:290
-            {
-                VmInput in{main_wl, normal, ray_d};
-                main_refl *= run_program(S, comp.color_program, in) * bounce_probability;
-                if (use_additional)
-                    for (uint32_t k = 0; k < n_add; ++k) {
-                        in.wavelength = spec.wl(k);
-                        spec.refl(k) *= run_program(S, comp.color_program, in) * bounce_probability;
+                ended = true;
+            } else {
+                // SurfaceBsdfType::scatter, materials/mod.rs:344-359
+                f3 out_direction;
+                float scatter_probability = 1.0f;
+                bool dispersed = false, has_brdf = false;
+                if (comp.bsdf == PYR_BSDF_DIFFUSE) { // diffuse.rs:8-25
+                    f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                    out_direction = sample_hemisphere(rng, n);
+                    has_brdf = true;
+                } else if (comp.bsdf == PYR_BSDF_MIRROR) { // mirror.rs:5-21
+                    f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                    float perp = dot(ray_d, n) * 2.0f;
+                    out_direction = ray_d - n * perp;
+                } else { // refractive.rs:6-37
+                    dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
+                    float ior = comp.ior, env_ior = comp.env_ior;
+                    if (dispersed) {
+                        float wl = main_wl * 0.001f;
+                        ior = comp.ior + comp.dispersion / (wl * wl);
+                        env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
                     }
-            }
+                    refract(ior, env_ior, ray_d, normal, rng, out_direction, scatter_probability);
+                }
 
-            // next-event estimation gate, tracer.rs:257-280
-            if (light_sample_events < 2) {
-                sample_light = !has_brdf || L.light_samples == 0;
-                if (has_brdf) {
-                    light_sample_events += 1;
-                    if (S.num_lamps > 0) { // trace_direct, tracer.rs:347-442
-                        const uint32_t lamp_index = rng_range_usize(rng, S.num_lamps); // pick_lamp, world.rs:301-305
-                        const DevLamp& lamp = S.lamps[lamp_index];
-                        const float lamp_probability = 1.0f / (float)S.num_lamps;
-                        const f3 nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                        const float probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
-                        for (uint32_t ls_i = 0; ls_i < L.light_samples; ++ls_i) {
-                            const LampSample ls = lamp_sample(lamp, rng, position);
-                            const float cos_out = fmaxf(dot(nff, ls.direction), 0.0f);
-                            if (!(cos_out > 0.0f)) continue;
-                            if (COUNT) cnt.shadow_rays++;
-                            const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
-                            Hit shadow_hit;
-#ifdef PYR_SHADOW_CLOSEST
-                            {
-                                bool has = traverse<COUNT, false>(S, position, ls.direction, limit, shadow_hit, stack, cnt);
-                                bool blocked = has && !(ls.sq_distance >= 0.0f && shadow_hit.t * shadow_hit.t >= ls.sq_distance - DIST_EPSILON);
-                                if (blocked) continue;
-                            }
-#else
-                            if (traverse<COUNT, true>(S, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
-#endif
-                            uint32_t l_color = ls.color;
-                            float material_probability = 1.0f;
-                            bool l_dispersed = false;
-                            f3 target_normal = -ls.direction;
-                            if (ls.physical) {
-                                const PyrMaterial lm = S.materials[ls.material];
-                                const uint32_t e_pick = rng_choose(rng, lm.num_emissive); // choose_emissive, materials/mod.rs:56-62
-                                const PyrComponent ec = S.components[lm.first_emissive + e_pick];
-                                material_probability = ec.selection_compensation;
-                                if (ec.probability_program >= 0) {
-                                    VmInput pin{main_wl, ls.normal, ls.direction};
-                                    material_probability = run_program(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
-                                    l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
+                // contribute, non-emission bounce, first half (algorithm.rs:48-63): reflectance *= color * probability
+                const float bounce_probability = scatter_probability * component_probability; // tracer.rs:296
+                use_additional = !(dispersed || normal_dispersed) && use_additional;           // simple.rs:122-123, tracer.rs:290
+                {
+                    VmInput in{main_wl, normal, ray_d};
+                    main_refl *= run_program(S, comp.color_program, in) * bounce_probability;
+                    if (use_additional)
+                        for (uint32_t k = 0; k < n_add; ++k) {
+                            in.wavelength = spec.wl(k);
+                            spec.refl(k) *= run_program(S, comp.color_program, in) * bounce_probability;
+                        }
+                }
+
+                // next-event estimation gate, tracer.rs:257-280
+                if (light_sample_events < 2) {
+                    sample_light = !has_brdf || L.light_samples == 0;
+                    if (has_brdf) {
+                        light_sample_events += 1;
+                        if (S.num_lamps > 0) { // trace_direct, tracer.rs:347-442
+                            const uint32_t lamp_index = rng_range_usize(rng, S.num_lamps); // pick_lamp, world.rs:301-305
+                            const DevLamp& lamp = S.lamps[lamp_index];
+                            const float lamp_probability = 1.0f / (float)S.num_lamps;
+                            const f3 nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                            const float probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                            for (uint32_t ls_i = 0; ls_i < L.light_samples; ++ls_i) {
+                                const LampSample ls = lamp_sample(lamp, rng, position);
+                                const float cos_out = fmaxf(dot(nff, ls.direction), 0.0f);
+                                if (!(cos_out > 0.0f)) continue;
+                                if (COUNT) cnt.shadow_rays++;
+                                const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
+                                Hit shadow_hit;
+                                if (traverse<COUNT, true>(S, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
+                                uint32_t l_color = ls.color;
+                                float material_probability = 1.0f;
+                                bool l_dispersed = false;
+                                f3 target_normal = -ls.direction;
+                                if (ls.physical) {
+                                    const PyrMaterial lm = S.materials[ls.material];
+                                    const uint32_t e_pick = rng_choose(rng, lm.num_emissive); // choose_emissive, materials/mod.rs:56-62
+                                    const PyrComponent ec = S.components[lm.first_emissive + e_pick];
+                                    material_probability = ec.selection_compensation;
+                                    if (ec.probability_program >= 0) {
+                                        VmInput pin{main_wl, ls.normal, ls.direction};
+                                        material_probability = run_program(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                                        l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
+                                    }
+                                    l_color = ec.color_program;
+                                    target_normal = ls.normal;
                                 }
-                                l_color = ec.color_program;
-                                target_normal = ls.normal;
+                                const float scale = ls.weight * probability * (2.0f * fabsf(dot(ls.direction, nff))); // lambertian, diffuse.rs:27-29
+                                const float l_probability = scale * material_probability;
+                                // contribute, direct light (algorithm.rs:65-90)
+                                VmInput in{main_wl, target_normal, ls.direction};
+                                main_bright += run_program(S, l_color, in) * l_probability * main_refl;
+                                if (use_additional && !l_dispersed)
+                                    for (uint32_t k = 0; k < n_add; ++k) {
+                                        in.wavelength = spec.wl(k);
+                                        spec.bright(k) += run_program(S, l_color, in) * l_probability * spec.refl(k);
+                                    }
                             }
-                            const float scale = ls.weight * probability * (2.0f * fabsf(dot(ls.direction, nff))); // lambertian, diffuse.rs:27-29
-                            const float l_probability = scale * material_probability;
-                            // contribute, direct light (algorithm.rs:65-90)
-                            VmInput in{main_wl, target_normal, ls.direction};
-                            main_bright += run_program(S, l_color, in) * l_probability * main_refl;
-                            if (use_additional && !l_dispersed)
-                                for (uint32_t k = 0; k < n_add; ++k) {
-                                    in.wavelength = spec.wl(k);
-                                    spec.bright(k) += run_program(S, l_color, in) * l_probability * spec.refl(k);
-                                }
                         }
                     }
+                } else {
+                    sample_light = true;
                 }
-            } else {
-                sample_light = true;
-            }
 
-            // contribute, second half (algorithm.rs:92-98): reflectance *= brdf (2|n.out| for diffuse, tracer.rs:175-183)
-            if (has_brdf) {
-                const float brdf = 2.0f * fabsf(dot(out_direction, normal));
-                main_refl *= brdf;
-                if (use_additional)
-                    for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+                // contribute, second half (algorithm.rs:92-98): reflectance *= brdf (2|n.out| for diffuse, tracer.rs:175-183)
+                if (has_brdf) {
+                    const float brdf = 2.0f * fabsf(dot(out_direction, normal));
+                    main_refl *= brdf;
+                    if (use_additional)
+                        for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+                }
+                ray_o = position;
+                ray_d = out_direction;
             }
-            ray_o = position;
-            ray_d = out_direction;
         }
 
-        // simple.rs:133-139
-        film_expose<COUNT>(L, px, py, main_wl, main_bright, cnt);
-        if (use_additional)
-            for (uint32_t k = 0; k < n_add; ++k) film_expose<COUNT>(L, px, py, spec.wl(k), spec.bright(k), cnt);
+        bounce++;
+        } while (!kRefillPerBounce && !ended && bounce < L.bounces);
+        if (ended || bounce >= L.bounces) {
+            // simple.rs:133-139
+            const long long pixel_base = film_pixel_base(L, px, py);
+            expose_grain<COUNT>(L, pixel_base, main_wl, main_bright, cnt);
+            if (use_additional)
+                for (uint32_t k = 0; k < n_add; ++k) expose_grain<COUNT>(L, pixel_base, spec.wl(k), spec.bright(k), cnt);
+            alive = false;
+        }
     }
     flush_counters<COUNT>(cnt, L.counters);
 }
@@ -1046,9 +1068,16 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
         return PYR_ERR_DEVICE;
     }
-    int blocks_per_cu = 0;
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, BLOCK, lds);
-    if (err != hipSuccess || blocks_per_cu < 1) blocks_per_cu = 1;
+    // Residency of a 256-thread block (one wave per SIMD): waves per SIMD allowed by the 512-entry register file (8-register
+    // granules, MI355X_MICROARCH.md "Register files") and by the 160 KB of LDS. The grid is persistent but needs no
+    // co-residency (no inter-block hand-off), so an over-estimate only queues blocks.
+    hipFuncAttributes attr{};
+    int blocks_per_cu = 4;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) == hipSuccess && attr.numRegs > 0) {
+        int regs = ((attr.numRegs + 7) / 8) * 8;
+        blocks_per_cu = std::min(8, 512 / regs);
+    }
+    blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
     uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
