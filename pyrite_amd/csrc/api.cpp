@@ -325,6 +325,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.rgb_max = d->rgb_basis_max;
     v.sky_program = d->sky_program;
     v.stack_depth = std::max(1u, bvh.max_depth);
+    v.needs_interpreter = 0;
+    for (const DevProgram& pr : programs)
+        if (pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast == FAST_NONE) v.needs_interpreter = 1;
 
     s->info.num_nodes = (uint32_t)bvh.nodes.size();
     s->info.num_leaves = bvh.num_leaves;

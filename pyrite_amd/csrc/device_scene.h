@@ -71,6 +71,7 @@ struct DevScene {
     float rgb_min, rgb_max;
     uint32_t sky_program;
     uint32_t stack_depth; // LDS stack entries per lane = BVH max depth
+    uint32_t needs_interpreter; // some program is neither a constant nor a fast shape
 };
 
 // Everything one render launch needs besides the scene.

@@ -332,6 +332,9 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
 }
 
 // ExecutionContext::run (execution_context.rs:29-56) with the three shapes every Cornell-family program has short-cut.
+// INTERP = false builds the kernel without the interpreter (and its register files in scratch) for scenes whose programs
+// are all constants or one of the fast shapes -- every BASELINE configuration; the host picks the variant per scene.
+template <bool INTERP>
 DEV float run_program(const DevScene& S, uint32_t id, const VmInput& in) {
     const DevProgram p = S.programs[id];
     if (p.kind == PYR_PROGRAM_CONSTANT) return p.constant;
@@ -339,7 +342,9 @@ DEV float run_program(const DevScene& S, uint32_t id, const VmInput& in) {
     case FAST_SPECTRUM: return spectrum_get(S, p.fast_spectrum, in.wavelength);
     case FAST_SPECTRUM_MUL: return spectrum_get(S, p.fast_spectrum, in.wavelength) * p.fast_scale;
     case FAST_MUL_SPECTRUM: return p.fast_scale * spectrum_get(S, p.fast_spectrum, in.wavelength);
-    default: return run_interpreter(S, p, in);
+    default:
+        if constexpr (INTERP) return run_interpreter(S, p, in);
+        return 0.0f;
     }
 }
 
@@ -769,7 +774,7 @@ DEV void expose_grain(const RenderLaunch& L, long long pixel_base, float wavelen
     if (COUNT) cnt.exposures++;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool INTERP>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
@@ -899,11 +904,11 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
                 }
             }
             VmInput in{main_wl, -ray_d, ray_d};
-            main_bright += run_program(S, color, in) * 1.0f * main_refl;
+            main_bright += run_program<INTERP>(S, color, in) * 1.0f * main_refl;
             if (use_additional)
                 for (uint32_t k = 0; k < n_add; ++k) {
                     in.wavelength = spec.wl(k);
-                    spec.bright(k) += run_program(S, color, in) * 1.0f * spec.refl(k);
+                    spec.bright(k) += run_program<INTERP>(S, color, in) * 1.0f * spec.refl(k);
                 }
             ended = true;
         } else {
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
             bool normal_dispersed = false;
             if (comp.probability_program >= 0) {
                 VmInput pin{main_wl, normal, ray_d};
-                component_probability = run_program(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+                component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
                 normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
             }
 
@@ -927,11 +932,11 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
                 if (sample_light) {
                     use_additional = !normal_dispersed && use_additional;
                     VmInput in{main_wl, normal, ray_d};
-                    main_bright += run_program(S, comp.color_program, in) * component_probability * main_refl;
+                    main_bright += run_program<INTERP>(S, comp.color_program, in) * component_probability * main_refl;
                     if (use_additional)
                         for (uint32_t k = 0; k < n_add; ++k) {
                             in.wavelength = spec.wl(k);
-                            spec.bright(k) += run_program(S, comp.color_program, in) * component_probability * spec.refl(k);
+                            spec.bright(k) += run_program<INTERP>(S, comp.color_program, in) * component_probability * spec.refl(k);
                         }
                 }
                 ended = true;
@@ -964,11 +969,11 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
                 use_additional = !(dispersed || normal_dispersed) && use_additional;           // simple.rs:122-123, tracer.rs:290
                 {
                     VmInput in{main_wl, normal, ray_d};
-                    main_refl *= run_program(S, comp.color_program, in) * bounce_probability;
+                    main_refl *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
                     if (use_additional)
                         for (uint32_t k = 0; k < n_add; ++k) {
                             in.wavelength = spec.wl(k);
-                            spec.refl(k) *= run_program(S, comp.color_program, in) * bounce_probability;
+                            spec.refl(k) *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
                         }
                 }
 
@@ -1002,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
                                     material_probability = ec.selection_compensation;
                                     if (ec.probability_program >= 0) {
                                         VmInput pin{main_wl, ls.normal, ls.direction};
-                                        material_probability = run_program(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                                        material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
                                         l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
                                     }
                                     l_color = ec.color_program;
@@ -1012,11 +1017,11 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
                                 const float l_probability = scale * material_probability;
                                 // contribute, direct light (algorithm.rs:65-90)
                                 VmInput in{main_wl, target_normal, ls.direction};
-                                main_bright += run_program(S, l_color, in) * l_probability * main_refl;
+                                main_bright += run_program<INTERP>(S, l_color, in) * l_probability * main_refl;
                                 if (use_additional && !l_dispersed)
                                     for (uint32_t k = 0; k < n_add; ++k) {
                                         in.wavelength = spec.wl(k);
-                                        spec.bright(k) += run_program(S, l_color, in) * l_probability * spec.refl(k);
+                                        spec.bright(k) += run_program<INTERP>(S, l_color, in) * l_probability * spec.refl(k);
                                     }
                             }
                         }
@@ -1062,7 +1067,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
         return PYR_ERR_UNSUPPORTED;
     }
-    auto kernel = with_counters ? render_kernel<true> : render_kernel<false>;
+    auto kernel = scene.needs_interpreter ? (with_counters ? render_kernel<true, true> : render_kernel<false, true>)
+                                          : (with_counters ? render_kernel<true, false> : render_kernel<false, false>);
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
