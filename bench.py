@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (development only: the line is then marked reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dev", default="", help="development overrides, e.g. spectrum_samples=1,light_samples=0,bounces=2 (marks the line reduced)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
 
@@ -123,6 +124,10 @@ def main():
     spp = args.spp or spp
     project = getattr(scenes, builder)(width=width, height=height, pixel_samples=spp)
     world, cam, renderer, _ = scenes.build(project, seed=args.seed)
+    for item in filter(None, args.dev.split(",")):
+        key, val = item.split("=")
+        setattr(renderer, key, int(val))
+        reduced = True
     world.scene(local_rank)  # BVH build + upload, outside the timed region
     bins = renderer.spectrum_bins
     film_desc = abi.PyrFilmDesc(width, height, bins, renderer.spectrum_span[0], renderer.spectrum_span[1] - renderer.spectrum_span[0])

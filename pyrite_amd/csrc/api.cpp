@@ -325,6 +325,8 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.rgb_max = d->rgb_basis_max;
     v.sky_program = d->sky_program;
     v.stack_depth = std::max(1u, bvh.max_depth);
+    v.num_nodes = (uint32_t)bvh.nodes.size();
+    v.num_prims = (uint32_t)prims.size();
     v.needs_interpreter = 0;
     for (const DevProgram& pr : programs)
         if (pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast == FAST_NONE) v.needs_interpreter = 1;

@@ -72,6 +72,7 @@ struct DevScene {
     uint32_t sky_program;
     uint32_t stack_depth; // LDS stack entries per lane = BVH max depth
     uint32_t needs_interpreter; // some program is neither a constant nor a fast shape
+    uint32_t num_nodes, num_prims;
 };
 
 // Everything one render launch needs besides the scene.

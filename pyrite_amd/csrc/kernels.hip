@@ -445,7 +445,7 @@ DEV float slab(f3 lo, f3 hi, f3 o, f3 inv) {
 // d > eps and d*d < limit" -- and returns as soon as one is found (equivalent to testing the closest hit, because
 // d -> d*d is monotonic). `limit` = lamp_distance^2 - eps, or +inf when the lamp has no distance.
 template <bool COUNT, bool SHADOW>
-DEV bool traverse(const DevScene& S, f3 o, f3 d, float limit, Hit& hit, int* stack, Counters& cnt) {
+DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f3 o, f3 d, float limit, Hit& hit, int* stack, Counters& cnt) {
     float closest = PYR_INF;
     hit.shape = PYR_HIT_NONE;
     hit.t = PYR_INF;
@@ -466,8 +466,6 @@ DEV bool traverse(const DevScene& S, f3 o, f3 d, float limit, Hit& hit, int* sta
         }
     }
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float4* nodes = reinterpret_cast<const float4*>(S.nodes);
-    const float4* prims = reinterpret_cast<const float4*>(S.prims);
     int sp = 0;
     int node = 0;
     for (;;) {
@@ -551,7 +549,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < L.n; i += gridDim.x * BLOCK) {
         const float* r = L.rays + 6 * (size_t)i;
         Hit hit;
-        traverse<COUNT, false>(S, ld3(r), ld3(r + 3), 0.0f, hit, stack, cnt);
+        traverse<COUNT, false>(S, reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), ld3(r), ld3(r + 3), 0.0f, hit, stack,
+                               cnt);
         PyrHit out;
         out.distance = hit.t;
         out.shape = hit.shape;
@@ -774,13 +773,27 @@ DEV void expose_grain(const RenderLaunch& L, long long pixel_base, float wavelen
     if (COUNT) cnt.exposures++;
 }
 
-template <bool COUNT, bool INTERP>
+template <bool COUNT, bool INTERP, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
     int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
     Counters cnt{};
+
+    // LDS_SCENE: a scene whose nodes + primitives fit in kLdsSceneBytes is staged into LDS once per workgroup and
+    // traversed from there (ds_read_b128 instead of L1/L2 round trips); larger scenes are read from HBM/L2 through float4 loads.
+    const float4* nodes = reinterpret_cast<const float4*>(S.nodes);
+    const float4* prims = reinterpret_cast<const float4*>(S.prims);
+    if constexpr (LDS_SCENE) {
+        float4* staged = reinterpret_cast<float4*>(lds + (3 * SS + S.stack_depth) * BLOCK);
+        const uint32_t node_vecs = S.num_nodes * 4, prim_vecs = S.num_prims * 3;
+        for (uint32_t i = threadIdx.x; i < node_vecs; i += BLOCK) staged[i] = nodes[i];
+        for (uint32_t i = threadIdx.x; i < prim_vecs; i += BLOCK) staged[node_vecs + i] = prims[i];
+        __syncthreads();
+        nodes = staged;
+        prims = staged + node_vecs;
+    }
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = BLOCK / 64;
@@ -890,7 +903,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
         do {
         Hit hit;
         if (COUNT) cnt.extension_rays++;
-        const bool found = traverse<COUNT, false>(S, ray_o, ray_d, 0.0f, hit, stack, cnt);
+        const bool found = traverse<COUNT, false>(S, nodes, prims, ray_o, ray_d, 0.0f, hit, stack, cnt);
         if (!found) {
             // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
             uint32_t color = S.sky_program;
@@ -995,7 +1008,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
                                 if (COUNT) cnt.shadow_rays++;
                                 const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
                                 Hit shadow_hit;
-                                if (traverse<COUNT, true>(S, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
+                                if (traverse<COUNT, true>(S, nodes, prims, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
                                 uint32_t l_color = ls.color;
                                 float material_probability = 1.0f;
                                 bool l_dispersed = false;
@@ -1057,8 +1070,12 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+constexpr size_t kLdsSceneBytes = 8 * 1024; // nodes + primitives staged in LDS when they fit (C1, C2: < 3 KB)
+static bool scene_fits_lds(const DevScene& scene) { return (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48 <= kLdsSceneBytes; }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
-    return (size_t)(3 * launch.spectrum_samples + scene.stack_depth) * BLOCK * sizeof(float);
+    size_t bytes = (size_t)(3 * launch.spectrum_samples + scene.stack_depth) * BLOCK * sizeof(float);
+    if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
+    return bytes;
 }
 
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus) {
@@ -1067,8 +1084,11 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
         return PYR_ERR_UNSUPPORTED;
     }
-    auto kernel = scene.needs_interpreter ? (with_counters ? render_kernel<true, true> : render_kernel<false, true>)
-                                          : (with_counters ? render_kernel<true, false> : render_kernel<false, false>);
+    using Kernel = void (*)(DevScene, RenderLaunch);
+    static const Kernel table[2][2][2] = {
+        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
+        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
+    Kernel kernel = table[with_counters ? 1 : 0][scene.needs_interpreter ? 1 : 0][scene_fits_lds(scene) ? 1 : 0];
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
