@@ -27,7 +27,6 @@ const char* kernels_last_error() { return g_kernel_error.c_str(); }
 #define DEV __device__ __forceinline__
 
 constexpr int BLOCK = 256;
-constexpr bool kRefillPerBounce = false;
 constexpr float DIST_EPSILON = 0.0001f; // math.rs:4
 constexpr float PI_F = 3.14159265358979323846f;
 #define PYR_INF __builtin_huge_valf()
@@ -773,6 +772,328 @@ DEV void expose_grain(const RenderLaunch& L, long long pixel_base, float wavelen
     if (COUNT) cnt.exposures++;
 }
 
+// Register-resident state of one path (the hero wavelength; the S-1 companions live in LDS, see Spectral).
+struct Path {
+    Rng rng;
+    float px, py;
+    f3 o, d;
+    float wl, bright, refl;
+    uint32_t bounce, events; // bounces made; light_sample_events (tracer.rs:219)
+    bool use_additional, sample_light;
+};
+
+// Scene pointers a workgroup traverses: HBM/L2, or the LDS copy when the scene is small (LDS_SCENE).
+struct SceneView {
+    const float4* nodes;
+    const float4* prims;
+};
+template <bool LDS_SCENE>
+DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_before) {
+    SceneView v{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
+    if constexpr (LDS_SCENE) {
+        float4* staged = reinterpret_cast<float4*>(lds + lds_floats_before);
+        const uint32_t node_vecs = S.num_nodes * 4, prim_vecs = S.num_prims * 3;
+        for (uint32_t i = threadIdx.x; i < node_vecs; i += BLOCK) staged[i] = v.nodes[i];
+        for (uint32_t i = threadIdx.x; i < prim_vecs; i += BLOCK) staged[node_vecs + i] = v.prims[i];
+        __syncthreads();
+        v.nodes = staged;
+        v.prims = staged + node_vecs;
+    }
+    return v;
+}
+
+// Start of render_tile's loop body (simple.rs:78-107) for iteration `iteration` of raster tile `tile`.
+DEV void start_sample(const RenderLaunch& L, uint32_t tile, uint64_t iteration, const TileArea& area, Path& p, Spectral& spec) {
+    const uint32_t SS = L.spectrum_samples;
+    p.rng = rng_seed(L.seed, tile, iteration);
+    // Tile::sample_point, renderer/algorithm.rs:113-119 (unfused: decides the pixel)
+    p.px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(p.rng)));
+    p.py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(p.rng)));
+    // Camera::ray_towards, cameras.rs:70-97
+    {
+        float focus_x = p.px / L.camera.view_plane * L.camera.focus_distance;
+        float focus_y = p.py / L.camera.view_plane * L.camera.focus_distance;
+        f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
+        f3 origin = mk(0, 0, 0), direction = target;
+        if (L.camera.aperture > 0.0f) {
+            float sqrt_r = sqrtf(L.camera.aperture * rng_f32(p.rng));
+            float psi = PI_F * 2.0f * rng_f32(p.rng);
+            origin = mk(sqrt_r * cos32(psi), sqrt_r * sin32(psi), 0.0f);
+            direction = target - origin;
+        }
+        p.o = transform_point(L.camera.cam_to_world, origin);
+        p.d = transform_vector(L.camera.cam_to_world, normalize(direction));
+    }
+    // Film::sample_many_wavelengths (film.rs:68-83) + hero pick by swap_remove (simple.rs:105-107)
+    {
+        float step_size = L.film.wl_width / (float)SS;
+        float from = L.film.wl_start;
+        for (uint32_t k = 0; k < SS; ++k) {
+            float to = __fadd_rn(from, step_size);
+            spec.wl(k) = rng_range_f32(p.rng, from, to);
+            from = to;
+        }
+        uint32_t hero = rng_range_usize(p.rng, SS);
+        p.wl = spec.wl(hero);
+        spec.wl(hero) = spec.wl(SS - 1);
+        for (uint32_t k = 0; k + 1 < SS; ++k) {
+            spec.bright(k) = 0.0f;
+            spec.refl(k) = 1.0f;
+        }
+    }
+    p.bright = 0.0f;
+    p.refl = 1.0f;
+    p.use_additional = true;
+    p.sample_light = true; // tracer.rs:218-219
+    p.events = 0;
+    p.bounce = 0;
+}
+
+// Maps an image-wide chunk number to (tile, first iteration, tile rectangle). Returns false when the lane's iteration lies
+// beyond the tile's iteration count (last chunk of a tile).
+DEV bool locate_chunk(const RenderLaunch& L, uint32_t chunk, uint32_t lane, uint32_t& tile, uint64_t& iteration, TileArea& area) {
+    const uint32_t row_chunks = (L.tiles_x - 1) * L.chunks_interior + L.chunks_right;
+    const uint32_t full_rows = L.tiles_y - 1;
+    uint32_t ty, r, per_tile;
+    if (chunk < full_rows * row_chunks) {
+        ty = chunk / row_chunks;
+        r = chunk - ty * row_chunks;
+        per_tile = L.chunks_interior;
+    } else {
+        ty = full_rows;
+        r = chunk - full_rows * row_chunks;
+        per_tile = L.chunks_bottom;
+    }
+    uint32_t tx = min(r / per_tile, L.tiles_x - 1);
+    uint32_t within = r - tx * per_tile;
+    tile = ty * L.tiles_x + tx;
+    uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
+    uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
+    uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
+    iteration = (uint64_t)within * 64u + lane;
+    if (iteration >= iterations) return false;
+    area = to_view_area(sx, sy, w, h, L.film.width, L.film.height);
+    return true;
+}
+
+// One iteration of tracer::trace's loop (tracer.rs:221-344) with `contribute` (renderer/algorithm.rs:14-100) applied online.
+// Returns true when the path has ended (emission, miss). Does not touch p.bounce.
+template <bool COUNT, bool INTERP>
+DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& view, Path& p, Spectral& spec, int* stack, Counters& cnt) {
+    const uint32_t n_add = L.spectrum_samples - 1;
+    Hit hit;
+    if (COUNT) cnt.extension_rays++;
+    const f3 ray_o = p.o, ray_d = p.d;
+    const bool found = traverse<COUNT, false>(S, view.nodes, view.prims, ray_o, ray_d, 0.0f, hit, stack, cnt);
+    if (!found) {
+        // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
+        uint32_t color = S.sky_program;
+        if (p.sample_light) {
+            for (uint32_t i = 0; i < S.num_lamps; ++i) {
+                const DevLamp& l = S.lamps[i];
+                if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
+                    color = l.color_program;
+                    break;
+                }
+            }
+        }
+        VmInput in{p.wl, -ray_d, ray_d};
+        p.bright += run_program<INTERP>(S, color, in) * 1.0f * p.refl;
+        if (p.use_additional)
+            for (uint32_t k = 0; k < n_add; ++k) {
+                in.wavelength = spec.wl(k);
+                spec.bright(k) += run_program<INTERP>(S, color, in) * 1.0f * spec.refl(k);
+            }
+        return true;
+    }
+    if (COUNT) cnt.shaded_hits++;
+    f3 position, normal;
+    uint32_t material_id;
+    surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
+    const PyrMaterial material = S.materials[material_id];
+    const uint32_t pick = rng_choose(p.rng, material.num_components); // choose_component, materials/mod.rs:48-54
+    const PyrComponent comp = S.components[material.first_component + pick];
+    // get_probability, materials/mod.rs:238-248
+    float component_probability = comp.selection_compensation;
+    bool normal_dispersed = false;
+    if (comp.probability_program >= 0) {
+        VmInput pin{p.wl, normal, ray_d};
+        component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+        normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
+    }
+
+    if (comp.bsdf == PYR_BSDF_EMISSIVE) { // Scattering::Emitted, tracer.rs:303-318
+        if (p.sample_light) {
+            p.use_additional = !normal_dispersed && p.use_additional;
+            VmInput in{p.wl, normal, ray_d};
+            p.bright += run_program<INTERP>(S, comp.color_program, in) * component_probability * p.refl;
+            if (p.use_additional)
+                for (uint32_t k = 0; k < n_add; ++k) {
+                    in.wavelength = spec.wl(k);
+                    spec.bright(k) += run_program<INTERP>(S, comp.color_program, in) * component_probability * spec.refl(k);
+                }
+        }
+        return true;
+    }
+
+    // SurfaceBsdfType::scatter, materials/mod.rs:344-359
+    f3 out_direction;
+    float scatter_probability = 1.0f;
+    bool dispersed = false, has_brdf = false;
+    if (comp.bsdf == PYR_BSDF_DIFFUSE) { // diffuse.rs:8-25
+        f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+        out_direction = sample_hemisphere(p.rng, n);
+        has_brdf = true;
+    } else if (comp.bsdf == PYR_BSDF_MIRROR) { // mirror.rs:5-21
+        f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+        float perp = dot(ray_d, n) * 2.0f;
+        out_direction = ray_d - n * perp;
+    } else { // refractive.rs:6-37
+        dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
+        float ior = comp.ior, env_ior = comp.env_ior;
+        if (dispersed) {
+            float wl = p.wl * 0.001f;
+            ior = comp.ior + comp.dispersion / (wl * wl);
+            env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
+        }
+        refract(ior, env_ior, ray_d, normal, p.rng, out_direction, scatter_probability);
+    }
+
+    // contribute, non-emission bounce, first half (algorithm.rs:48-63): reflectance *= color * probability
+    const float bounce_probability = scatter_probability * component_probability; // tracer.rs:296
+    p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;       // simple.rs:122-123, tracer.rs:290
+    {
+        VmInput in{p.wl, normal, ray_d};
+        p.refl *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+        if (p.use_additional)
+            for (uint32_t k = 0; k < n_add; ++k) {
+                in.wavelength = spec.wl(k);
+                spec.refl(k) *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+            }
+    }
+
+    // next-event estimation gate, tracer.rs:257-280
+    if (p.events < 2) {
+        p.sample_light = !has_brdf || L.light_samples == 0;
+        if (has_brdf) {
+            p.events += 1;
+            if (S.num_lamps > 0) { // trace_direct, tracer.rs:347-442
+                const uint32_t lamp_index = rng_range_usize(p.rng, S.num_lamps); // pick_lamp, world.rs:301-305
+                const DevLamp& lamp = S.lamps[lamp_index];
+                const float lamp_probability = 1.0f / (float)S.num_lamps;
+                const f3 nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                const float probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                for (uint32_t ls_i = 0; ls_i < L.light_samples; ++ls_i) {
+                    const LampSample ls = lamp_sample(lamp, p.rng, position);
+                    const float cos_out = fmaxf(dot(nff, ls.direction), 0.0f);
+                    if (!(cos_out > 0.0f)) continue;
+                    if (COUNT) cnt.shadow_rays++;
+                    const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
+                    Hit shadow_hit;
+                    if (traverse<COUNT, true>(S, view.nodes, view.prims, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
+                    uint32_t l_color = ls.color;
+                    float material_probability = 1.0f;
+                    bool l_dispersed = false;
+                    f3 target_normal = -ls.direction;
+                    if (ls.physical) {
+                        const PyrMaterial lm = S.materials[ls.material];
+                        const uint32_t e_pick = rng_choose(p.rng, lm.num_emissive); // choose_emissive, materials/mod.rs:56-62
+                        const PyrComponent ec = S.components[lm.first_emissive + e_pick];
+                        material_probability = ec.selection_compensation;
+                        if (ec.probability_program >= 0) {
+                            VmInput pin{p.wl, ls.normal, ls.direction};
+                            material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                            l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
+                        }
+                        l_color = ec.color_program;
+                        target_normal = ls.normal;
+                    }
+                    const float scale = ls.weight * probability * (2.0f * fabsf(dot(ls.direction, nff))); // lambertian, diffuse.rs:27-29
+                    const float l_probability = scale * material_probability;
+                    // contribute, direct light (algorithm.rs:65-90)
+                    VmInput in{p.wl, target_normal, ls.direction};
+                    p.bright += run_program<INTERP>(S, l_color, in) * l_probability * p.refl;
+                    if (p.use_additional && !l_dispersed)
+                        for (uint32_t k = 0; k < n_add; ++k) {
+                            in.wavelength = spec.wl(k);
+                            spec.bright(k) += run_program<INTERP>(S, l_color, in) * l_probability * spec.refl(k);
+                        }
+                }
+            }
+        }
+    } else {
+        p.sample_light = true;
+    }
+
+    // contribute, second half (algorithm.rs:92-98): reflectance *= brdf (2|n.out| for diffuse, tracer.rs:175-183)
+    if (has_brdf) {
+        const float brdf = 2.0f * fabsf(dot(out_direction, normal));
+        p.refl *= brdf;
+        if (p.use_additional)
+            for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+    }
+    p.o = position;
+    p.d = out_direction;
+    return false;
+}
+
+// simple.rs:133-139: expose the hero always, the companions unless a bounce dispersed.
+template <bool COUNT>
+DEV void finish_path(const RenderLaunch& L, const Path& p, Spectral& spec, Counters& cnt) {
+    const long long pixel_base = film_pixel_base(L, p.px, p.py);
+    expose_grain<COUNT>(L, pixel_base, p.wl, p.bright, cnt);
+    if (p.use_additional)
+        for (uint32_t k = 0; k + 1 < L.spectrum_samples; ++k) expose_grain<COUNT>(L, pixel_base, spec.wl(k), spec.bright(k), cnt);
+}
+
+// ---- the tail queue: paths that survive the head's bounces, parked in HBM as structure-of-arrays [field][slot]
+constexpr uint32_t kTailScalarFields = 17; // rng 4, px py 2, o 3, d 3, wl bright refl 3, bounce, events|flags
+DEV uint32_t tail_fields(uint32_t spectrum_samples) { return kTailScalarFields + 3 * (spectrum_samples - 1); }
+
+DEV void tail_store(float* q, uint32_t cap, uint32_t slot, const Path& p, Spectral& spec, uint32_t SS) {
+    float* f = q + slot;
+    auto put = [&](uint32_t field, float v) { f[(size_t)field * cap] = v; };
+    put(0, __uint_as_float(p.rng.x));
+    put(1, __uint_as_float(p.rng.y));
+    put(2, __uint_as_float(p.rng.z));
+    put(3, __uint_as_float(p.rng.w));
+    put(4, p.px);
+    put(5, p.py);
+    put(6, p.o.x), put(7, p.o.y), put(8, p.o.z);
+    put(9, p.d.x), put(10, p.d.y), put(11, p.d.z);
+    put(12, p.wl), put(13, p.bright), put(14, p.refl);
+    put(15, __uint_as_float(p.bounce));
+    put(16, __uint_as_float(p.events | (p.use_additional ? 4u : 0u) | (p.sample_light ? 8u : 0u)));
+    for (uint32_t k = 0; k + 1 < SS; ++k) {
+        put(kTailScalarFields + 3 * k + 0, spec.wl(k));
+        put(kTailScalarFields + 3 * k + 1, spec.bright(k));
+        put(kTailScalarFields + 3 * k + 2, spec.refl(k));
+    }
+}
+DEV void tail_load(const float* q, uint32_t cap, uint32_t slot, Path& p, Spectral& spec, uint32_t SS) {
+    const float* f = q + slot;
+    auto get = [&](uint32_t field) { return f[(size_t)field * cap]; };
+    p.rng = Rng{__float_as_uint(get(0)), __float_as_uint(get(1)), __float_as_uint(get(2)), __float_as_uint(get(3))};
+    p.px = get(4), p.py = get(5);
+    p.o = mk(get(6), get(7), get(8));
+    p.d = mk(get(9), get(10), get(11));
+    p.wl = get(12), p.bright = get(13), p.refl = get(14);
+    p.bounce = __float_as_uint(get(15));
+    uint32_t packed = __float_as_uint(get(16));
+    p.events = packed & 3u;
+    p.use_additional = (packed & 4u) != 0;
+    p.sample_light = (packed & 8u) != 0;
+    for (uint32_t k = 0; k + 1 < SS; ++k) {
+        spec.wl(k) = get(kTailScalarFields + 3 * k + 0);
+        spec.bright(k) = get(kTailScalarFields + 3 * k + 1);
+        spec.refl(k) = get(kTailScalarFields + 3 * k + 2);
+    }
+}
+
+// HEAD kernel: sample generation and the first `head_bounces` bounces, walked bounce-synchronously by the wave -- that
+// is where next-event estimation happens (first two diffuse events, tracer.rs:257), and all 64 lanes want it at the same
+// time. Paths that are still alive afterwards are compacted into the tail queue (one wave-aggregated atomic per wave:
+// ballot + prefix count give each surviving lane its slot); the rest expose their spectra.
 template <bool COUNT, bool INTERP, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaunch L) {
     extern __shared__ float lds[];
@@ -780,292 +1101,96 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
     Spectral spec{lds + threadIdx.x, SS};
     int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
     Counters cnt{};
-
-    // LDS_SCENE: a scene whose nodes + primitives fit in kLdsSceneBytes is staged into LDS once per workgroup and
-    // traversed from there (ds_read_b128 instead of L1/L2 round trips); larger scenes are read from HBM/L2 through float4 loads.
-    const float4* nodes = reinterpret_cast<const float4*>(S.nodes);
-    const float4* prims = reinterpret_cast<const float4*>(S.prims);
-    if constexpr (LDS_SCENE) {
-        float4* staged = reinterpret_cast<float4*>(lds + (3 * SS + S.stack_depth) * BLOCK);
-        const uint32_t node_vecs = S.num_nodes * 4, prim_vecs = S.num_prims * 3;
-        for (uint32_t i = threadIdx.x; i < node_vecs; i += BLOCK) staged[i] = nodes[i];
-        for (uint32_t i = threadIdx.x; i < prim_vecs; i += BLOCK) staged[node_vecs + i] = prims[i];
-        __syncthreads();
-        nodes = staged;
-        prims = staged + node_vecs;
-    }
+    const SceneView view = stage_scene<LDS_SCENE>(S, lds, (3 * SS + S.stack_depth) * BLOCK);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = BLOCK / 64;
     const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t total_waves = gridDim.x * waves_per_block;
-    uint32_t chunk = L.chunk_begin + wave; // this lane's next chunk; lanes advance independently
-    const uint32_t n_add = SS - 1;
+    const uint32_t head_bounces = min(L.bounces, L.head_bounces);
 
-    // Per-path state. With kRefillPerBounce a loop iteration is ONE bounce and a lane whose path has ended starts its next
-    // sample at once; without it a wave walks its 64 paths bounce-synchronously. Measured on C2 (MI355X, 64 spp): refilling
-    // per bounce is 0.6x the speed -- it spreads the next-event-estimation section (4 shadow rays, run for the first two
-    // diffuse events only) over every iteration at ~40 % lane occupancy, where the synchronous walk runs it twice per
-    // batch at full occupancy and skips it afterwards. Kept for the record; the queue-based scheduler replaces both.
-    bool alive = false;
-    Rng rng{};
-    float px = 0.0f, py = 0.0f;
-    f3 ray_o = mk(0, 0, 0), ray_d = mk(0, 0, 1);
-    float main_wl = 0.0f, main_bright = 0.0f, main_refl = 1.0f;
-    bool use_additional = true, sample_light = true;
-    uint32_t light_sample_events = 0, bounce = 0;
-
-    for (;;) {
-        if (!alive) {
-            // ---- next sample of this lane: iteration (chunk - first chunk of its tile) * 64 + lane
-            uint32_t tile = 0;
-            uint64_t iteration = 0;
-            TileArea area{};
-            while (chunk < L.chunk_end) {
-                const uint32_t row_chunks = (L.tiles_x - 1) * L.chunks_interior + L.chunks_right;
-                const uint32_t full_rows = L.tiles_y - 1;
-                uint32_t ty, r, per_tile;
-                if (chunk < full_rows * row_chunks) {
-                    ty = chunk / row_chunks;
-                    r = chunk - ty * row_chunks;
-                    per_tile = L.chunks_interior;
-                } else {
-                    ty = full_rows;
-                    r = chunk - full_rows * row_chunks;
-                    per_tile = L.chunks_bottom;
-                }
-                uint32_t tx = min(r / per_tile, L.tiles_x - 1);
-                uint32_t within = r - tx * per_tile;
-                tile = ty * L.tiles_x + tx;
-                uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
-                uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
-                uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
-                iteration = (uint64_t)within * 64u + lane;
-                chunk += total_waves;
-                if (iteration < iterations) {
-                    area = to_view_area(sx, sy, w, h, L.film.width, L.film.height);
-                    alive = true;
-                    break;
-                }
-            }
-            if (!alive) break; // no work left for this lane
-
-            rng = rng_seed(L.seed, tile, iteration);
+    for (uint32_t chunk = L.chunk_begin + wave; chunk < L.chunk_end; chunk += total_waves) {
+        uint32_t tile;
+        uint64_t iteration;
+        TileArea area;
+        bool alive = locate_chunk(L, chunk, lane, tile, iteration, area);
+        Path p{};
+        if (alive) {
+            start_sample(L, tile, iteration, area, p, spec);
             if (COUNT) cnt.samples++;
-
-            // Tile::sample_point, renderer/algorithm.rs:113-119 (unfused: decides the pixel)
-            px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(rng)));
-            py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(rng)));
-
-            // Camera::ray_towards, cameras.rs:70-97
-            {
-                float focus_x = px / L.camera.view_plane * L.camera.focus_distance;
-                float focus_y = py / L.camera.view_plane * L.camera.focus_distance;
-                f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
-                f3 origin = mk(0, 0, 0), direction = target;
-                if (L.camera.aperture > 0.0f) {
-                    float sqrt_r = sqrtf(L.camera.aperture * rng_f32(rng));
-                    float psi = PI_F * 2.0f * rng_f32(rng);
-                    origin = mk(sqrt_r * cos32(psi), sqrt_r * sin32(psi), 0.0f);
-                    direction = target - origin;
-                }
-                ray_o = transform_point(L.camera.cam_to_world, origin);
-                ray_d = transform_vector(L.camera.cam_to_world, normalize(direction));
-            }
-
-            // Film::sample_many_wavelengths (film.rs:68-83) + hero pick by swap_remove (simple.rs:105-107)
-            {
-                float step_size = L.film.wl_width / (float)SS;
-                float from = L.film.wl_start;
-                for (uint32_t k = 0; k < SS; ++k) {
-                    float to = __fadd_rn(from, step_size);
-                    spec.wl(k) = rng_range_f32(rng, from, to);
-                    from = to;
-                }
-                uint32_t hero = rng_range_usize(rng, SS);
-                main_wl = spec.wl(hero);
-                spec.wl(hero) = spec.wl(SS - 1);
-                for (uint32_t k = 0; k + 1 < SS; ++k) {
-                    spec.bright(k) = 0.0f;
-                    spec.refl(k) = 1.0f;
-                }
-            }
-            main_bright = 0.0f;
-            main_refl = 1.0f;
-            use_additional = true;
-            sample_light = true; // tracer.rs:218-219
-            light_sample_events = 0;
-            bounce = 0;
         }
-
-        // ---- one bounce of tracer::trace (tracer.rs:221-344) with `contribute` (renderer/algorithm.rs:14-100) applied online
-        bool ended = false;
-        do {
-        Hit hit;
-        if (COUNT) cnt.extension_rays++;
-        const bool found = traverse<COUNT, false>(S, nodes, prims, ray_o, ray_d, 0.0f, hit, stack, cnt);
-        if (!found) {
-            // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
-            uint32_t color = S.sky_program;
-            if (sample_light) {
-                for (uint32_t i = 0; i < S.num_lamps; ++i) {
-                    const DevLamp& l = S.lamps[i];
-                    if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
-                        color = l.color_program;
-                        break;
-                    }
-                }
+        const bool started = alive;
+        while (alive && p.bounce < head_bounces) {
+            const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt);
+            p.bounce++;
+            if (ended) alive = false;
+        }
+        const bool to_tail = alive && p.bounce < L.bounces;
+        // wave-level compaction of the survivors into the tail queue
+        const unsigned long long mask = __ballot(to_tail);
+        if (mask != 0) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(L.tail_count, (uint32_t)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (to_tail) {
+                uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                tail_store(L.tail_queue, L.tail_capacity, slot, p, spec, SS);
             }
-            VmInput in{main_wl, -ray_d, ray_d};
-            main_bright += run_program<INTERP>(S, color, in) * 1.0f * main_refl;
-            if (use_additional)
-                for (uint32_t k = 0; k < n_add; ++k) {
-                    in.wavelength = spec.wl(k);
-                    spec.bright(k) += run_program<INTERP>(S, color, in) * 1.0f * spec.refl(k);
-                }
-            ended = true;
-        } else {
-            if (COUNT) cnt.shaded_hits++;
-            f3 position, normal;
-            uint32_t material_id;
-            surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
-            const PyrMaterial material = S.materials[material_id];
-            const uint32_t pick = rng_choose(rng, material.num_components); // choose_component, materials/mod.rs:48-54
-            const PyrComponent comp = S.components[material.first_component + pick];
-            // get_probability, materials/mod.rs:238-248
-            float component_probability = comp.selection_compensation;
-            bool normal_dispersed = false;
-            if (comp.probability_program >= 0) {
-                VmInput pin{main_wl, normal, ray_d};
-                component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
-                normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
-            }
+        }
+        if (started && !to_tail) finish_path<COUNT>(L, p, spec, cnt);
+    }
+    flush_counters<COUNT>(cnt, L.counters);
+}
 
-            if (comp.bsdf == PYR_BSDF_EMISSIVE) { // Scattering::Emitted, tracer.rs:303-318
-                if (sample_light) {
-                    use_additional = !normal_dispersed && use_additional;
-                    VmInput in{main_wl, normal, ray_d};
-                    main_bright += run_program<INTERP>(S, comp.color_program, in) * component_probability * main_refl;
-                    if (use_additional)
-                        for (uint32_t k = 0; k < n_add; ++k) {
-                            in.wavelength = spec.wl(k);
-                            spec.bright(k) += run_program<INTERP>(S, comp.color_program, in) * component_probability * spec.refl(k);
-                        }
-                }
-                ended = true;
-            } else {
-                // SurfaceBsdfType::scatter, materials/mod.rs:344-359
-                f3 out_direction;
-                float scatter_probability = 1.0f;
-                bool dispersed = false, has_brdf = false;
-                if (comp.bsdf == PYR_BSDF_DIFFUSE) { // diffuse.rs:8-25
-                    f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                    out_direction = sample_hemisphere(rng, n);
-                    has_brdf = true;
-                } else if (comp.bsdf == PYR_BSDF_MIRROR) { // mirror.rs:5-21
-                    f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                    float perp = dot(ray_d, n) * 2.0f;
-                    out_direction = ray_d - n * perp;
-                } else { // refractive.rs:6-37
-                    dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
-                    float ior = comp.ior, env_ior = comp.env_ior;
-                    if (dispersed) {
-                        float wl = main_wl * 0.001f;
-                        ior = comp.ior + comp.dispersion / (wl * wl);
-                        env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
-                    }
-                    refract(ior, env_ior, ray_d, normal, rng, out_direction, scatter_probability);
-                }
+// TAIL kernel: the remaining bounces of the parked paths. No lane waits for another path here: a lane whose path ends
+// exposes it and pulls the next parked path at once (strided slots), so occupancy stays full while path lengths differ.
+template <bool COUNT, bool INTERP, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK, 4) void tail_kernel(DevScene S, RenderLaunch L) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    Spectral spec{lds + threadIdx.x, SS};
+    int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
+    Counters cnt{};
+    const SceneView view = stage_scene<LDS_SCENE>(S, lds, (3 * SS + S.stack_depth) * BLOCK);
 
-                // contribute, non-emission bounce, first half (algorithm.rs:48-63): reflectance *= color * probability
-                const float bounce_probability = scatter_probability * component_probability; // tracer.rs:296
-                use_additional = !(dispersed || normal_dispersed) && use_additional;           // simple.rs:122-123, tracer.rs:290
-                {
-                    VmInput in{main_wl, normal, ray_d};
-                    main_refl *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
-                    if (use_additional)
-                        for (uint32_t k = 0; k < n_add; ++k) {
-                            in.wavelength = spec.wl(k);
-                            spec.refl(k) *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
-                        }
+    const uint32_t count = *L.tail_count;
+    const uint32_t stride = gridDim.x * BLOCK;
+    uint32_t next = blockIdx.x * BLOCK + threadIdx.x;
+    // Lane states: alive (has a path to advance), pending (its path ended and still has to be exposed), exhausted (no parked
+    // path left for it). Exposing a path and loading the next one are "service" work that only a few lanes need per
+    // iteration; run for one lane it costs the whole wave. So ended lanes wait until kServiceLanes of them have piled up
+    // (or nothing else is left to do) and are then serviced together.
+    constexpr int kServiceLanes = 16;
+    bool alive = false, pending = false, exhausted = false;
+    Path p{};
+    for (;;) {
+        const int idle = __popcll(__ballot(!alive));
+        if (idle >= kServiceLanes || idle == 64) {
+            if (!alive) {
+                if (pending) {
+                    finish_path<COUNT>(L, p, spec, cnt);
+                    pending = false;
                 }
-
-                // next-event estimation gate, tracer.rs:257-280
-                if (light_sample_events < 2) {
-                    sample_light = !has_brdf || L.light_samples == 0;
-                    if (has_brdf) {
-                        light_sample_events += 1;
-                        if (S.num_lamps > 0) { // trace_direct, tracer.rs:347-442
-                            const uint32_t lamp_index = rng_range_usize(rng, S.num_lamps); // pick_lamp, world.rs:301-305
-                            const DevLamp& lamp = S.lamps[lamp_index];
-                            const float lamp_probability = 1.0f / (float)S.num_lamps;
-                            const f3 nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                            const float probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
-                            for (uint32_t ls_i = 0; ls_i < L.light_samples; ++ls_i) {
-                                const LampSample ls = lamp_sample(lamp, rng, position);
-                                const float cos_out = fmaxf(dot(nff, ls.direction), 0.0f);
-                                if (!(cos_out > 0.0f)) continue;
-                                if (COUNT) cnt.shadow_rays++;
-                                const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
-                                Hit shadow_hit;
-                                if (traverse<COUNT, true>(S, nodes, prims, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
-                                uint32_t l_color = ls.color;
-                                float material_probability = 1.0f;
-                                bool l_dispersed = false;
-                                f3 target_normal = -ls.direction;
-                                if (ls.physical) {
-                                    const PyrMaterial lm = S.materials[ls.material];
-                                    const uint32_t e_pick = rng_choose(rng, lm.num_emissive); // choose_emissive, materials/mod.rs:56-62
-                                    const PyrComponent ec = S.components[lm.first_emissive + e_pick];
-                                    material_probability = ec.selection_compensation;
-                                    if (ec.probability_program >= 0) {
-                                        VmInput pin{main_wl, ls.normal, ls.direction};
-                                        material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
-                                        l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
-                                    }
-                                    l_color = ec.color_program;
-                                    target_normal = ls.normal;
-                                }
-                                const float scale = ls.weight * probability * (2.0f * fabsf(dot(ls.direction, nff))); // lambertian, diffuse.rs:27-29
-                                const float l_probability = scale * material_probability;
-                                // contribute, direct light (algorithm.rs:65-90)
-                                VmInput in{main_wl, target_normal, ls.direction};
-                                main_bright += run_program<INTERP>(S, l_color, in) * l_probability * main_refl;
-                                if (use_additional && !l_dispersed)
-                                    for (uint32_t k = 0; k < n_add; ++k) {
-                                        in.wavelength = spec.wl(k);
-                                        spec.bright(k) += run_program<INTERP>(S, l_color, in) * l_probability * spec.refl(k);
-                                    }
-                            }
-                        }
-                    }
+                if (next < count) {
+                    tail_load(L.tail_queue, L.tail_capacity, next, p, spec, SS);
+                    next += stride;
+                    alive = true;
                 } else {
-                    sample_light = true;
+                    exhausted = true;
                 }
-
-                // contribute, second half (algorithm.rs:92-98): reflectance *= brdf (2|n.out| for diffuse, tracer.rs:175-183)
-                if (has_brdf) {
-                    const float brdf = 2.0f * fabsf(dot(out_direction, normal));
-                    main_refl *= brdf;
-                    if (use_additional)
-                        for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
-                }
-                ray_o = position;
-                ray_d = out_direction;
             }
+            if (__ballot(alive) == 0) break; // every lane exhausted and nothing pending
         }
-
-        bounce++;
-        } while (!kRefillPerBounce && !ended && bounce < L.bounces);
-        if (ended || bounce >= L.bounces) {
-            // simple.rs:133-139
-            const long long pixel_base = film_pixel_base(L, px, py);
-            expose_grain<COUNT>(L, pixel_base, main_wl, main_bright, cnt);
-            if (use_additional)
-                for (uint32_t k = 0; k < n_add; ++k) expose_grain<COUNT>(L, pixel_base, spec.wl(k), spec.bright(k), cnt);
-            alive = false;
+        if (alive) {
+            const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt);
+            p.bounce++;
+            if (ended || p.bounce >= L.bounces) {
+                alive = false;
+                pending = true;
+            }
         }
     }
+    (void)exhausted;
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -1078,42 +1203,58 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
     return bytes;
 }
 
+uint32_t tail_queue_fields(uint32_t spectrum_samples) { return kTailScalarFields + 3 * (spectrum_samples - 1); }
+
+using RenderKernel = void (*)(DevScene, RenderLaunch);
+static RenderKernel pick_kernel(bool tail, bool with_counters, bool interp, bool lds_scene) {
+    static const RenderKernel head[2][2][2] = {
+        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
+        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
+    static const RenderKernel tails[2][2][2] = {
+        {{tail_kernel<false, false, false>, tail_kernel<false, false, true>}, {tail_kernel<false, true, false>, tail_kernel<false, true, true>}},
+        {{tail_kernel<true, false, false>, tail_kernel<true, false, true>}, {tail_kernel<true, true, false>, tail_kernel<true, true, true>}}};
+    return (tail ? tails : head)[with_counters ? 1 : 0][interp ? 1 : 0][lds_scene ? 1 : 0];
+}
+
+// Launches the head kernel over [chunk_begin, chunk_end) and then the tail kernel over whatever the head parked.
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus) {
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
         return PYR_ERR_UNSUPPORTED;
     }
-    using Kernel = void (*)(DevScene, RenderLaunch);
-    static const Kernel table[2][2][2] = {
-        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
-        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
-    Kernel kernel = table[with_counters ? 1 : 0][scene.needs_interpreter ? 1 : 0][scene_fits_lds(scene) ? 1 : 0];
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (err != hipSuccess) {
-        g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
-        return PYR_ERR_DEVICE;
-    }
-    // Residency of a 256-thread block (one wave per SIMD): waves per SIMD allowed by the 512-entry register file (8-register
-    // granules, MI355X_MICROARCH.md "Register files") and by the 160 KB of LDS. The grid is persistent but needs no
-    // co-residency (no inter-block hand-off), so an over-estimate only queues blocks.
-    hipFuncAttributes attr{};
-    int blocks_per_cu = 4;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) == hipSuccess && attr.numRegs > 0) {
-        int regs = ((attr.numRegs + 7) / 8) * 8;
-        blocks_per_cu = std::min(8, 512 / regs);
-    }
-    blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
-    uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
-    uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
-    if (grid > blocks_needed) grid = blocks_needed;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
-    err = hipGetLastError();
-    if (err != hipSuccess) {
-        g_kernel_error = std::string("render kernel launch: ") + hipGetErrorString(err);
-        return PYR_ERR_DEVICE;
+    for (int tail = 0; tail < 2; ++tail) {
+        RenderKernel kernel = pick_kernel(tail != 0, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene));
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) {
+            g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
+            return PYR_ERR_DEVICE;
+        }
+        // Residency of a 256-thread block (one wave per SIMD): waves per SIMD allowed by the 512-entry register file
+        // (8-register granules, MI355X_MICROARCH.md "Register files") and by the 160 KB of LDS. The grids are persistent but
+        // need no co-residency (no inter-block hand-off), so an over-estimate only queues blocks.
+        hipFuncAttributes attr{};
+        int blocks_per_cu = 4;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) == hipSuccess && attr.numRegs > 0) {
+            int regs = ((attr.numRegs + 7) / 8) * 8;
+            blocks_per_cu = std::min(8, 512 / regs);
+        }
+        blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+        uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
+        if (tail == 0) {
+            uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
+            if (grid > blocks_needed) grid = blocks_needed;
+        } else if (launch.head_bounces >= launch.bounces) {
+            break; // the head walks every bounce: nothing is ever parked
+        }
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
+        err = hipGetLastError();
+        if (err != hipSuccess) {
+            g_kernel_error = std::string("render kernel launch: ") + hipGetErrorString(err);
+            return PYR_ERR_DEVICE;
+        }
     }
     return PYR_OK;
 }
