@@ -465,6 +465,7 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
         }
     }
     const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float limit_cull = limit * 1.001f + 1.0e-3f; // +inf stays +inf
     int sp = 0;
     int node = 0;
     for (;;) {
@@ -474,8 +475,13 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
         float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), o, inv);
         bool h0, h1;
         if (SHADOW) {
-            h0 = e0 >= 0.0f && e0 * e0 < limit;
-            h1 = e1 >= 0.0f && e1 * e1 < limit;
+            // A box can be skipped only if nothing in it can block. Its computed entry distance and a primitive's computed
+            // hit distance are independent roundings of (at best) the same number -- for a zero-thickness box they differ
+            // by ulps either way -- so the cut-off keeps a 0.1 % margin over the blocking limit instead of comparing against
+            // it exactly (found on C3: at scene scale 50, d^2 ~ 2500 has an ulp of 2.4e-4 > DIST_EPSILON and an exact
+            // comparison skipped lamp triangles the reference tests).
+            h0 = e0 >= 0.0f && e0 * e0 < limit_cull;
+            h1 = e1 >= 0.0f && e1 * e1 < limit_cull;
         } else {
             h0 = e0 >= 0.0f && e0 < closest; // bvh.rs:213: skip when distance >= max_distance
             h1 = e1 >= 0.0f && e1 < closest;

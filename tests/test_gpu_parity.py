@@ -142,6 +142,27 @@ def test_closest_hit_on_a_dense_mesh(gpu_lib):
     assert (ohits["shape"] != 0xFFFFFFFF).mean() > 0.1
 
 
+@pytest.mark.parametrize("glass", [False, True])
+def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
+    """C3 / C5 in small: the x10 Cornell box with a (coarser) torus-knot mesh, diffuse or dispersive glass. At this scale
+    d^2 ~ 2500 has an ulp larger than DIST_EPSILON, which is where an exact box cut-off for shadow rays once diverged from
+    the reference's closest-hit visibility test."""
+    from pyrite_amd.renderer import Camera, Renderer, World
+
+    project = scenes.c3_mesh_in_box(width=64, height=36, pixel_samples=4, glass=glass, bounces=20 if glass else None)
+    world = World(scenes.c3_flat(segments=96, sides=48, glass=glass))
+    r = Renderer.from_project(project["renderer"], seed=6)
+    cam = Camera.from_project(project["camera"])
+    gfilm, cfilm = r.new_film(64, 36), r.new_film(64, 36)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    gcount = r.render(gfilm, cam, world, counters=True)
+    assert_parity(gfilm, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+    if glass:
+        assert gcount["exposures"] < gcount["samples"] * 10  # dispersed paths expose the hero wavelength only
+
+
 @pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example"])
 def test_gpu_reproduces_the_committed_golden_films(name, gpu_lib):
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
