@@ -336,6 +336,15 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.stack_depth = std::max(1u, bvh.max_depth);
     v.num_nodes = (uint32_t)bvh.nodes.size();
     v.num_prims = (uint32_t)prims.size();
+    v.num_spectra = d->num_spectra;
+    v.num_spectrum_floats = d->num_spectrum_floats;
+    {
+        const uint32_t floats = d->num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float)) + d->num_spectrum_floats;
+        // <= 12 KB, and only for scenes too big to live in LDS themselves: a small scene leaves L1 to the tables (C2: staging
+        // them costs a workgroup per CU and is 0.9x), a big one evicts them all the time (C3: staging them is 1.33x)
+        const bool big_scene = (size_t)bvh.nodes.size() * 64 + prims.size() * 48 > 8 * 1024;
+        v.lds_table_floats = (floats <= 3072 && big_scene) ? floats : 0;
+    }
     v.needs_interpreter = 0;
     for (const DevProgram& pr : programs)
         if (pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast == FAST_NONE) v.needs_interpreter = 1;
@@ -409,6 +418,14 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     const uint32_t total_chunks = L.chunk_end - L.chunk_begin;
     if (total_chunks == 0) return PYR_OK;
     L.head_bounces = head_bounces_setting();
+    {
+        const char* e = std::getenv("PYRITE_SCHEDULER"); // "sync" | "sm"
+        L.scheduler = (e && std::string(e) == "sm") ? 1u : 0u;
+        const char* lanes = std::getenv("PYRITE_SM_LANES");
+        const char* steps = std::getenv("PYRITE_SM_STEPS");
+        L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
+        L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
+    }
     const uint32_t fields = tail_queue_fields(L.spectrum_samples);
     const uint64_t want = std::min<uint64_t>((uint64_t)total_chunks * 64, kMaxBatchPaths);
     if (L.bounces > L.head_bounces && (scene->tail_capacity < want || scene->tail_fields != fields)) {
@@ -569,7 +586,9 @@ int pyr_scene_counters(PyrScene* scene, PyrCounters* out) {
 int pyr_scene_intersect_device(PyrScene* scene, const float* rays_device, uint32_t n, PyrHit* hits_device, void* hip_stream) {
     if (!scene || (n && (!rays_device || !hits_device))) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(scene->device));
-    IntersectLaunch L{rays_device, hits_device, n, nullptr};
+    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(scene->tail_count, 0, sizeof(uint32_t), (hipStream_t)hip_stream));
+    IntersectLaunch L{rays_device, hits_device, n, nullptr, scene->tail_count, (uint32_t)scene->num_cus};
     int rc = launch_intersect(scene->dev, L, false, hip_stream);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());
     return PYR_OK;
@@ -585,8 +604,10 @@ int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* 
     int rc;
     if ((rc = rays_dev.upload(rays, (size_t)n * 24)) != PYR_OK) return rc;
     if ((rc = hits_dev.alloc((size_t)n * sizeof(PyrHit))) != PYR_OK) return rc;
-    IntersectLaunch L{(const float*)rays_dev.ptr, (PyrHit*)hits_dev.ptr, n, nullptr};
+    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, sizeof(uint32_t)));
+    IntersectLaunch L{(const float*)rays_dev.ptr, (PyrHit*)hits_dev.ptr, n, nullptr, scene->tail_count, (uint32_t)scene->num_cus};
     if (counters) {
+        HIP_TRY(hipMemset(scene->tail_count, 0, sizeof(uint32_t)));
         HIP_TRY(hipMemset(scene->counters.ptr, 0, sizeof(PyrCounters)));
         L.counters = (unsigned long long*)scene->counters.ptr;
         rc = launch_intersect(scene->dev, L, true, nullptr);
@@ -598,6 +619,7 @@ int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* 
     hipEvent_t start, stop;
     HIP_TRY(hipEventCreate(&start));
     HIP_TRY(hipEventCreate(&stop));
+    HIP_TRY(hipMemset(scene->tail_count, 0, sizeof(uint32_t)));
     HIP_TRY(hipEventRecord(start, nullptr));
     rc = launch_intersect(scene->dev, L, false, nullptr);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());

@@ -73,6 +73,8 @@ struct DevScene {
     uint32_t stack_depth; // LDS stack entries per lane = BVH max depth
     uint32_t needs_interpreter; // some program is neither a constant nor a fast shape
     uint32_t num_nodes, num_prims;
+    uint32_t num_spectra, num_spectrum_floats;
+    uint32_t lds_table_floats; // > 0: the spectrum tables are staged into LDS (this many floats)
 };
 
 // Everything one render launch needs besides the scene.
@@ -93,6 +95,8 @@ struct RenderLaunch {
     unsigned long long* counters; // 9 words (PyrCounters order) or nullptr
     // Tail queue (kernels.hip): paths alive after `head_bounces` bounces are parked in `tail_queue`
     // ([tail_queue_fields(S)][tail_capacity] floats) and finished by the tail kernel; *tail_count is zero at launch.
+    uint32_t scheduler; // 0 = bounce-synchronous head (+ optional tail), 1 = stage-scheduled state machine
+    uint32_t sm_phase_lanes, sm_trav_steps; // stage scheduler: lanes that make a phase run; traversal steps per turn
     uint32_t head_bounces;
     uint32_t tail_capacity;
     float* tail_queue;
@@ -104,6 +108,9 @@ struct IntersectLaunch {
     PyrHit* hits;
     uint32_t n;
     unsigned long long* counters;
+    uint32_t* next;  // device word, zero at launch: the next ray of the batch to hand out
+    uint32_t num_cus;
+    uint32_t reserve; // rays a wave reserves per atomic (set by launch_intersect)
 };
 
 // launchers (kernels.hip)

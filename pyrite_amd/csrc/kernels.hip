@@ -545,27 +545,6 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
     return hit.shape != PYR_HIT_NONE;
 }
 
-// ------------------------------------------------------------------------------------------------ intersect kernel
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectLaunch L) {
-    extern __shared__ int lds_stack[];
-    int* stack = lds_stack + threadIdx.x;
-    Counters cnt{};
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < L.n; i += gridDim.x * BLOCK) {
-        const float* r = L.rays + 6 * (size_t)i;
-        Hit hit;
-        traverse<COUNT, false>(S, reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), ld3(r), ld3(r + 3), 0.0f, hit, stack,
-                               cnt);
-        PyrHit out;
-        out.distance = hit.t;
-        out.shape = hit.shape;
-        out.u = hit.u;
-        out.v = hit.v;
-        L.hits[i] = out;
-    }
-    flush_counters<COUNT>(cnt, L.counters);
-}
-
 // ------------------------------------------------------------------------------------------------ camera / film mapping
 struct TileArea {
     float from_x, from_y, size_x, size_y;
@@ -806,6 +785,26 @@ DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_bef
         v.prims = staged + node_vecs;
     }
     return v;
+}
+
+// Spectrum tables (PyrSpectrum records + sample data) are small and read with a different index by every lane and
+// wavelength: on C3 the BVH traffic evicts them from L1 and every lookup becomes two dependent L2 round trips (measured:
+// the 10-wavelength work cost 139 of 250 ms). When they fit they are copied into LDS once per workgroup; the scene copy
+// handed to the device functions then points at the LDS copy (generic pointers: the loads become flat loads that resolve
+// to LDS).
+DEV DevScene stage_tables(const DevScene& S, float* lds, uint32_t lds_floats_before) {
+    DevScene local = S;
+    if (S.lds_table_floats != 0) {
+        float* dst = lds + lds_floats_before;
+        const uint32_t rec_floats = S.num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float));
+        const float* rec_src = reinterpret_cast<const float*>(S.spectra);
+        for (uint32_t i = threadIdx.x; i < rec_floats; i += BLOCK) dst[i] = rec_src[i];
+        for (uint32_t i = threadIdx.x; i < S.num_spectrum_floats; i += BLOCK) dst[rec_floats + i] = S.spectrum_data[i];
+        __syncthreads();
+        local.spectra = reinterpret_cast<const PyrSpectrum*>(dst);
+        local.spectrum_data = dst + rec_floats;
+    }
+    return local;
 }
 
 // Start of render_tile's loop body (simple.rs:78-107) for iteration `iteration` of raster tile `tile`.
@@ -1101,13 +1100,15 @@ DEV void tail_load(const float* q, uint32_t cap, uint32_t slot, Path& p, Spectra
 // time. Paths that are still alive afterwards are compacted into the tail queue (one wave-aggregated atomic per wave:
 // ballot + prefix count give each surviving lane its slot); the rest expose their spectra.
 template <bool COUNT, bool INTERP, bool LDS_SCENE>
-__global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaunch L) {
+__global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
     int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
     Counters cnt{};
-    const SceneView view = stage_scene<LDS_SCENE>(S, lds, (3 * SS + S.stack_depth) * BLOCK);
+    const uint32_t lds_base_floats = (3 * SS + S0.stack_depth) * BLOCK;
+    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
+    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = BLOCK / 64;
@@ -1151,13 +1152,15 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S, RenderLaun
 // TAIL kernel: the remaining bounces of the parked paths. No lane waits for another path here: a lane whose path ends
 // exposes it and pulls the next parked path at once (strided slots), so occupancy stays full while path lengths differ.
 template <bool COUNT, bool INTERP, bool LDS_SCENE>
-__global__ __launch_bounds__(BLOCK, 4) void tail_kernel(DevScene S, RenderLaunch L) {
+__global__ __launch_bounds__(BLOCK, 4) void tail_kernel(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
     int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
     Counters cnt{};
-    const SceneView view = stage_scene<LDS_SCENE>(S, lds, (3 * SS + S.stack_depth) * BLOCK);
+    const uint32_t lds_base_floats = (3 * SS + S0.stack_depth) * BLOCK;
+    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
+    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
 
     const uint32_t count = *L.tail_count;
     const uint32_t stride = gridDim.x * BLOCK;
@@ -1200,18 +1203,489 @@ __global__ __launch_bounds__(BLOCK, 4) void tail_kernel(DevScene S, RenderLaunch
     flush_counters<COUNT>(cnt, L.counters);
 }
 
+// =================================================================================================
+// Stage-scheduled integrator (render_kernel_sm)
+//
+// The bounce-synchronous walk above makes every lane wait for the slowest lane of each phase: on C3 (819 k triangles)
+// the traversal of a ray that enters the mesh takes ~5x the steps of one that hits a wall and lane occupancy drops to 14 %
+// (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU); on C2 it is 33 %. Here every lane runs its path as a state machine
+// whose states are the phases of render_tile / trace / trace_direct:
+//     NEW -> TRAV(ext) -> SHADE -> { NEE -> TRAV(shadow) -> NEE ... } -> TRAV(ext) ... -> EXPOSE -> NEW
+// and the WAVE decides, from ballots, which phase code to run next: a phase runs when at least sm_phase_lanes lanes wait for
+// it, or when it is the most wanted one. Traversal is resumable (node index, stack pointer and closest hit stay in
+// registers, the stack in LDS) and advances sm_trav_steps node/leaf steps per turn, so a lane that finishes a short ray goes
+// on to shading while its neighbours keep walking the tree, and a lane whose path ends refills itself with the next
+// sample. Results are those of the synchronous walk bit for bit: per-path order of operations and RNG draws is unchanged.
+// =================================================================================================
+enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EXPOSE = 4, ST_DONE = 5 };
+
+struct Trav { // resumable World::intersect
+    f3 o, d, inv;
+    float limit, limit_cull, closest;
+    int node, sp;
+    uint32_t shape;
+    float u, v;
+    bool shadow, blocked;
+};
+
+// Planes first (world.rs:277-285), then the tree from the root. Returns true when the query is already decided.
+template <bool COUNT>
+DEV bool trav_begin(const DevScene& S, Trav& t, f3 o, f3 d, bool shadow, float limit, Counters& cnt) {
+    t.o = o;
+    t.d = d;
+    t.shadow = shadow;
+    t.blocked = false;
+    t.limit = limit;
+    t.limit_cull = limit * 1.001f + 1.0e-3f;
+    t.closest = PYR_INF;
+    t.shape = PYR_HIT_NONE;
+    t.u = t.v = 0.0f;
+    for (uint32_t i = 0; i < S.num_planes; ++i) {
+        const float* pl = S.planes + 8 * i;
+        float dist;
+        f3 point;
+        if (COUNT) cnt.plane_tests++;
+        if (plane_test(ld3(pl), ld3(pl + 3), o, d, dist, point)) {
+            if (shadow) {
+                if (dist > DIST_EPSILON && dist * dist < limit) {
+                    t.blocked = true;
+                    return true;
+                }
+            } else if (dist > DIST_EPSILON && dist < t.closest) {
+                t.closest = dist;
+                t.shape = ((uint32_t)PYR_SHAPE_PLANE << 30) | i;
+            }
+        }
+    }
+    t.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    t.node = 0;
+    t.sp = 0;
+    return false;
+}
+
+// One node visit or one leaf. Returns true when the traversal has finished. Same tests, same order as traverse<>.
+template <bool COUNT>
+DEV bool trav_step(const SceneView& view, Trav& t, int* stack, Counters& cnt) {
+    if (t.node >= 0) {
+        const float4* nd = view.nodes + 4 * t.node;
+        const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+        if (COUNT) cnt.box_tests += 2;
+        const float e0 = slab(mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z), t.o, t.inv);
+        const float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), t.o, t.inv);
+        bool h0, h1;
+        if (t.shadow) {
+            h0 = e0 >= 0.0f && e0 * e0 < t.limit_cull;
+            h1 = e1 >= 0.0f && e1 * e1 < t.limit_cull;
+        } else {
+            h0 = e0 >= 0.0f && e0 < t.closest;
+            h1 = e1 >= 0.0f && e1 < t.closest;
+        }
+        const int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+        if (h0 && h1) {
+            const bool swap = e1 < e0;
+            t.node = swap ? c1 : c0;
+            stack[t.sp * BLOCK] = swap ? c0 : c1;
+            t.sp++;
+        } else if (h0) {
+            t.node = c0;
+        } else if (h1) {
+            t.node = c1;
+        } else {
+            if (t.sp == 0) return true;
+            t.sp--;
+            t.node = stack[t.sp * BLOCK];
+        }
+        return false;
+    }
+    const uint32_t code = (uint32_t)(-1 - t.node);
+    const uint32_t first = code >> 3, count = code & 7u;
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 a = view.prims[3 * (first + k) + 0], b = view.prims[3 * (first + k) + 1];
+        const uint32_t shape = __float_as_uint(a.w);
+        float dist, u = 0.0f, v = 0.0f;
+        bool ok;
+        if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
+            const float4 c = view.prims[3 * (first + k) + 2];
+            if (COUNT) cnt.triangle_tests++;
+            ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t.o, t.d, dist, u, v);
+        } else {
+            f3 point;
+            if (COUNT) cnt.sphere_tests++;
+            ok = sphere_test(mk(a.x, a.y, a.z), b.x, t.o, t.d, dist, point);
+        }
+        if (ok) {
+            if (t.shadow) {
+                if (dist > DIST_EPSILON && dist * dist < t.limit) {
+                    t.blocked = true;
+                    return true;
+                }
+            } else if (dist > DIST_EPSILON && dist < t.closest) {
+                t.closest = dist;
+                t.shape = shape;
+                t.u = u;
+                t.v = v;
+            }
+        }
+    }
+    if (t.sp == 0) return true;
+    t.sp--;
+    t.node = stack[t.sp * BLOCK];
+    return false;
+}
+
+template <bool COUNT, bool INTERP, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, RenderLaunch L) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    const uint32_t n_add = SS - 1;
+    Spectral spec{lds + threadIdx.x, SS};
+    int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
+    Counters cnt{};
+    const uint32_t lds_base_floats = (3 * SS + S0.stack_depth) * BLOCK;
+    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
+    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = BLOCK / 64;
+    const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    uint32_t chunk = L.chunk_begin + wave;
+
+    const int phase_lanes = (int)L.sm_phase_lanes, trav_steps = (int)L.sm_trav_steps;
+    uint32_t stage = ST_NEW;
+    Path p{};
+    Trav t{};
+    // context of the bounce in flight (between SHADE and the end of its next-event estimation)
+    f3 b_position = mk(0, 0, 0), b_normal = mk(0, 0, 0), b_out = mk(0, 0, 0), b_nff = mk(0, 0, 0);
+    bool b_has_brdf = false;
+    uint32_t nee_lamp = 0, nee_i = 0;
+    float nee_probability = 0.0f;
+    // the light sample whose shadow ray is in flight
+    bool ls_pending = false, ls_physical = false;
+    uint32_t ls_material = 0, ls_color = 0;
+    f3 ls_normal = mk(0, 0, 0);
+    float ls_scale = 0.0f;
+
+    // tracer.rs:288-301 tail of a bounce + loop head :221: reflectance *= brdf, next ray, bounce count
+    auto finish_bounce = [&]() {
+        if (b_has_brdf) {
+            const float brdf = 2.0f * fabsf(dot(b_out, b_normal));
+            p.refl *= brdf;
+            if (p.use_additional)
+                for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+        }
+        p.o = b_position;
+        p.d = b_out;
+        p.bounce++;
+        if (p.bounce >= L.bounces) {
+            stage = ST_EXPOSE;
+        } else {
+            if (COUNT) cnt.extension_rays++;
+            stage = trav_begin<COUNT>(S, t, p.o, p.d, false, 0.0f, cnt) ? ST_SHADE : ST_TRAV;
+        }
+    };
+
+    for (;;) {
+        const int nT = __popcll(__ballot(stage == ST_TRAV));
+        const int nS = __popcll(__ballot(stage == ST_SHADE));
+        const int nN = __popcll(__ballot(stage == ST_NEE));
+        const int nE = __popcll(__ballot(stage == ST_EXPOSE || stage == ST_NEW));
+        const int best = max(max(nT, nS), max(nN, nE));
+        if (best == 0) break; // every lane is DONE
+
+        // ---- EXPOSE / NEW: finish the path (simple.rs:133-139) and start the next sample (simple.rs:78-107)
+        if (nE >= phase_lanes || nE == best) {
+            if (stage == ST_EXPOSE) {
+                finish_path<COUNT>(L, p, spec, cnt);
+                stage = ST_NEW;
+            }
+            if (stage == ST_NEW) {
+                stage = ST_DONE;
+                while (chunk < L.chunk_end) {
+                    uint32_t tile;
+                    uint64_t iteration;
+                    TileArea area;
+                    const bool ok = locate_chunk(L, chunk, lane, tile, iteration, area);
+                    chunk += total_waves;
+                    if (ok) {
+                        start_sample(L, tile, iteration, area, p, spec);
+                        if (COUNT) cnt.samples++;
+                        if (L.bounces == 0) {
+                            stage = ST_EXPOSE;
+                        } else {
+                            if (COUNT) cnt.extension_rays++;
+                            stage = trav_begin<COUNT>(S, t, p.o, p.d, false, 0.0f, cnt) ? ST_SHADE : ST_TRAV;
+                        }
+                        break;
+                    }
+                }
+            }
+        }
+
+        // ---- SHADE: the hit/miss handling of tracer::trace (tracer.rs:222-341) up to the start of next-event estimation
+        if (nS >= phase_lanes || nS == best) {
+            if (stage == ST_SHADE) {
+                const f3 ray_o = t.o, ray_d = t.d;
+                if (t.shape == PYR_HIT_NONE) {
+                    uint32_t color = S.sky_program;
+                    if (p.sample_light) {
+                        for (uint32_t i = 0; i < S.num_lamps; ++i) {
+                            const DevLamp& l = S.lamps[i];
+                            if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
+                                color = l.color_program;
+                                break;
+                            }
+                        }
+                    }
+                    VmInput in{p.wl, -ray_d, ray_d};
+                    p.bright += run_program<INTERP>(S, color, in) * 1.0f * p.refl;
+                    if (p.use_additional)
+                        for (uint32_t k = 0; k < n_add; ++k) {
+                            in.wavelength = spec.wl(k);
+                            spec.bright(k) += run_program<INTERP>(S, color, in) * 1.0f * spec.refl(k);
+                        }
+                    stage = ST_EXPOSE;
+                } else {
+                    if (COUNT) cnt.shaded_hits++;
+                    Hit hit{t.closest, t.shape, t.u, t.v};
+                    f3 position, normal;
+                    uint32_t material_id;
+                    surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
+                    const PyrMaterial material = S.materials[material_id];
+                    const uint32_t pick = rng_choose(p.rng, material.num_components);
+                    const PyrComponent comp = S.components[material.first_component + pick];
+                    float component_probability = comp.selection_compensation;
+                    bool normal_dispersed = false;
+                    if (comp.probability_program >= 0) {
+                        VmInput pin{p.wl, normal, ray_d};
+                        component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+                        normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
+                    }
+                    if (comp.bsdf == PYR_BSDF_EMISSIVE) {
+                        if (p.sample_light) {
+                            p.use_additional = !normal_dispersed && p.use_additional;
+                            VmInput in{p.wl, normal, ray_d};
+                            p.bright += run_program<INTERP>(S, comp.color_program, in) * component_probability * p.refl;
+                            if (p.use_additional)
+                                for (uint32_t k = 0; k < n_add; ++k) {
+                                    in.wavelength = spec.wl(k);
+                                    spec.bright(k) += run_program<INTERP>(S, comp.color_program, in) * component_probability * spec.refl(k);
+                                }
+                        }
+                        stage = ST_EXPOSE;
+                    } else {
+                        f3 out_direction;
+                        float scatter_probability = 1.0f;
+                        bool dispersed = false, has_brdf = false;
+                        if (comp.bsdf == PYR_BSDF_DIFFUSE) {
+                            f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                            out_direction = sample_hemisphere(p.rng, n);
+                            has_brdf = true;
+                        } else if (comp.bsdf == PYR_BSDF_MIRROR) {
+                            f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                            float perp = dot(ray_d, n) * 2.0f;
+                            out_direction = ray_d - n * perp;
+                        } else {
+                            dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
+                            float ior = comp.ior, env_ior = comp.env_ior;
+                            if (dispersed) {
+                                float wl = p.wl * 0.001f;
+                                ior = comp.ior + comp.dispersion / (wl * wl);
+                                env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
+                            }
+                            refract(ior, env_ior, ray_d, normal, p.rng, out_direction, scatter_probability);
+                        }
+                        const float bounce_probability = scatter_probability * component_probability;
+                        p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
+                        {
+                            VmInput in{p.wl, normal, ray_d};
+                            p.refl *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+                            if (p.use_additional)
+                                for (uint32_t k = 0; k < n_add; ++k) {
+                                    in.wavelength = spec.wl(k);
+                                    spec.refl(k) *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+                                }
+                        }
+                        b_position = position;
+                        b_normal = normal;
+                        b_out = out_direction;
+                        b_has_brdf = has_brdf;
+                        bool nee = false;
+                        if (p.events < 2) { // tracer.rs:257-280
+                            p.sample_light = !has_brdf || L.light_samples == 0;
+                            if (has_brdf) {
+                                p.events += 1;
+                                if (S.num_lamps > 0) {
+                                    nee_lamp = rng_range_usize(p.rng, S.num_lamps); // pick_lamp, world.rs:301-305
+                                    const float lamp_probability = 1.0f / (float)S.num_lamps;
+                                    b_nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                                    nee_probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                                    nee_i = 0;
+                                    ls_pending = false;
+                                    nee = true;
+                                }
+                            }
+                        } else {
+                            p.sample_light = true;
+                        }
+                        if (nee)
+                            stage = ST_NEE;
+                        else
+                            finish_bounce();
+                    }
+                }
+            }
+        }
+
+        // ---- NEE: trace_direct (tracer.rs:347-442), one light sample per visit: account for the shadow ray that came back,
+        //      then draw the next sample that needs one
+        if (nN >= phase_lanes || nN == best) {
+            if (stage == ST_NEE) {
+                if (ls_pending) {
+                    ls_pending = false;
+                    if (!t.blocked) {
+                        uint32_t l_color = ls_color;
+                        float material_probability = 1.0f;
+                        bool l_dispersed = false;
+                        f3 target_normal = -t.d;
+                        if (ls_physical) {
+                            const PyrMaterial lm = S.materials[ls_material];
+                            const uint32_t e_pick = rng_choose(p.rng, lm.num_emissive);
+                            const PyrComponent ec = S.components[lm.first_emissive + e_pick];
+                            material_probability = ec.selection_compensation;
+                            if (ec.probability_program >= 0) {
+                                VmInput pin{p.wl, ls_normal, t.d};
+                                material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                                l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
+                            }
+                            l_color = ec.color_program;
+                            target_normal = ls_normal;
+                        }
+                        const float l_probability = ls_scale * material_probability;
+                        VmInput in{p.wl, target_normal, t.d};
+                        p.bright += run_program<INTERP>(S, l_color, in) * l_probability * p.refl;
+                        if (p.use_additional && !l_dispersed)
+                            for (uint32_t k = 0; k < n_add; ++k) {
+                                in.wavelength = spec.wl(k);
+                                spec.bright(k) += run_program<INTERP>(S, l_color, in) * l_probability * spec.refl(k);
+                            }
+                    }
+                }
+                const DevLamp& lamp = S.lamps[nee_lamp];
+                while (nee_i < L.light_samples) {
+                    const LampSample ls = lamp_sample(lamp, p.rng, b_position);
+                    nee_i++;
+                    const float cos_out = fmaxf(dot(b_nff, ls.direction), 0.0f);
+                    if (!(cos_out > 0.0f)) continue;
+                    if (COUNT) cnt.shadow_rays++;
+                    const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
+                    ls_scale = ls.weight * nee_probability * (2.0f * fabsf(dot(ls.direction, b_nff)));
+                    ls_physical = ls.physical;
+                    ls_material = ls.material;
+                    ls_color = ls.color;
+                    ls_normal = ls.normal;
+                    ls_pending = true;
+                    // a shadow ray decided by a plane alone comes straight back to this phase
+                    stage = trav_begin<COUNT>(S, t, b_position, ls.direction, true, limit, cnt) ? ST_NEE : ST_TRAV;
+                    break;
+                }
+                if (stage == ST_NEE && !ls_pending) finish_bounce();
+            }
+        }
+
+        // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
+        if (nT >= phase_lanes || nT == best) {
+            for (int step = 0; step < trav_steps; ++step) {
+                if (stage == ST_TRAV) {
+                    if (trav_step<COUNT>(view, t, stack, cnt)) stage = t.shadow ? ST_NEE : ST_SHADE;
+                }
+            }
+        }
+    }
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ------------------------------------------------------------------------------------------------ intersect kernel
+// World::intersect for a batch of rays: persistent waves with dynamic ray fetch. A lane that finishes its ray does not
+// wait for the slowest ray of the wave: when kRefillLanes lanes are idle the wave takes that many rays from the batch with
+// ONE atomic (ballot + prefix count hand each idle lane its ray) and goes on stepping. On C3 the ray lengths are heavy
+// tailed (most rays see 3-6 nodes, rays that graze the mesh 50-100); a one-ray-per-lane kernel ran at 7 % lane occupancy.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectLaunch L) {
+    extern __shared__ int lds_stack[];
+    int* stack = lds_stack + threadIdx.x;
+    Counters cnt{};
+    const SceneView view{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr int kRefillLanes = 16, kSteps = 4;
+    const uint32_t kReserve = L.reserve; // rays a wave takes from the batch per atomic (one word serves only ~88 M atomics/s)
+    bool busy = false;
+    uint32_t ray = 0;
+    Trav t{};
+    uint32_t res_next = 0, res_end = 0; // this wave's reserved slice of the batch (wave-uniform)
+    bool drained = false;               // the batch has been handed out completely and the reserve is empty
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!busy);
+        const int idle = __popcll(idle_mask);
+        if (!drained && (idle >= kRefillLanes || idle == 64)) {
+            if (res_next == res_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(L.next, kReserve);
+                base = __shfl(base, 0, 64);
+                res_next = min(base, L.n);
+                res_end = min(base + kReserve, L.n);
+                if (res_next == res_end) drained = true;
+            }
+            if (!drained) {
+                const uint32_t available = res_end - res_next;
+                const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (!busy && rank < available) {
+                    ray = res_next + rank;
+                    const float* r = L.rays + 6 * (size_t)ray;
+                    trav_begin<COUNT>(S, t, ld3(r), ld3(r + 3), false, 0.0f, cnt);
+                    busy = true;
+                }
+                res_next += min((uint32_t)idle, available);
+            }
+        }
+        if (__ballot(busy) == 0) {
+            if (drained) break;
+            continue;
+        }
+        for (int step = 0; step < kSteps; ++step) {
+            if (busy && trav_step<COUNT>(view, t, stack, cnt)) {
+                PyrHit out;
+                out.distance = t.shape != PYR_HIT_NONE ? t.closest : PYR_INF;
+                out.shape = t.shape;
+                out.u = t.u;
+                out.v = t.v;
+                L.hits[ray] = out;
+                busy = false;
+            }
+        }
+    }
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 constexpr size_t kLdsSceneBytes = 8 * 1024; // nodes + primitives staged in LDS when they fit (C1, C2: < 3 KB)
 static bool scene_fits_lds(const DevScene& scene) { return (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48 <= kLdsSceneBytes; }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     size_t bytes = (size_t)(3 * launch.spectrum_samples + scene.stack_depth) * BLOCK * sizeof(float);
     if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
+    bytes += (size_t)scene.lds_table_floats * sizeof(float);
     return bytes;
 }
 
 uint32_t tail_queue_fields(uint32_t spectrum_samples) { return kTailScalarFields + 3 * (spectrum_samples - 1); }
 
 using RenderKernel = void (*)(DevScene, RenderLaunch);
+static RenderKernel pick_sm_kernel(bool with_counters, bool interp, bool lds_scene) {
+    static const RenderKernel sm[2][2][2] = {
+        {{render_kernel_sm<false, false, false>, render_kernel_sm<false, false, true>}, {render_kernel_sm<false, true, false>, render_kernel_sm<false, true, true>}},
+        {{render_kernel_sm<true, false, false>, render_kernel_sm<true, false, true>}, {render_kernel_sm<true, true, false>, render_kernel_sm<true, true, true>}}};
+    return sm[with_counters ? 1 : 0][interp ? 1 : 0][lds_scene ? 1 : 0];
+}
 static RenderKernel pick_kernel(bool tail, bool with_counters, bool interp, bool lds_scene) {
     static const RenderKernel head[2][2][2] = {
         {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
@@ -1232,7 +1706,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
     for (int tail = 0; tail < 2; ++tail) {
-        RenderKernel kernel = pick_kernel(tail != 0, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene));
+        RenderKernel kernel = launch.scheduler == 1 ? pick_sm_kernel(with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene))
+                                                    : pick_kernel(tail != 0, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene));
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) {
             g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
@@ -1252,8 +1727,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
         if (tail == 0) {
             uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
             if (grid > blocks_needed) grid = blocks_needed;
-        } else if (launch.head_bounces >= launch.bounces) {
-            break; // the head walks every bounce: nothing is ever parked
+        } else if (launch.scheduler == 1 || launch.head_bounces >= launch.bounces) {
+            break; // no tail launch: the stage scheduler / the head walks every bounce
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
         err = hipGetLastError();
@@ -1274,9 +1749,16 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
         return PYR_ERR_DEVICE;
     }
-    uint32_t grid = (launch.n + BLOCK - 1) / BLOCK;
-    if (grid > 256 * 8) grid = 256 * 8;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
+    // persistent grid: as many workgroups as the registers and the LDS stack let a CU hold (no co-residency is required)
+    int blocks_per_cu = std::max(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+    uint32_t grid = (uint32_t)launch.num_cus * (uint32_t)blocks_per_cu;
+    uint32_t needed = (launch.n + BLOCK - 1) / BLOCK;
+    if (grid > needed) grid = needed;
+    IntersectLaunch sized = launch;
+    // reservation per atomic: about a quarter of a wave's share of the batch, a multiple of 64, at most 2048
+    const uint32_t waves = grid * (BLOCK / 64);
+    sized.reserve = std::max<uint32_t>(64, std::min<uint32_t>(2048, (launch.n / std::max<uint32_t>(waves * 4, 1)) & ~63u));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, sized);
     err = hipGetLastError();
     if (err != hipSuccess) {
         g_kernel_error = std::string("intersect kernel launch: ") + hipGetErrorString(err);
