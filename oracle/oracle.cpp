@@ -33,13 +33,82 @@ constexpr float DIST_EPSILON = 0.0001f; // math.rs:4
 constexpr float PI = 3.14159265358979323846f; // std::f32::consts::PI
 constexpr float INF = std::numeric_limits<float>::infinity();
 
-// Transcendentals. Rust's f32::sin / cos / acos / exp / atan2 call the platform libm (sinf, ...), whose results are
-// within an ulp of, but not always equal to, the correctly rounded value and differ between libms. The oracle and
-// the HIP kernels both evaluate them through f64 and round once -- the correctly rounded f32 result up to the
-// (about 1e-8 per call) double-rounding cases -- so that the two sides agree bit for bit (DESIGN.md "Arithmetic").
-inline float sin32(float x) { return (float)std::sin((double)x); }
-inline float cos32(float x) { return (float)std::cos((double)x); }
-inline float acos32(float x) { return (float)std::acos((double)x); }
+// Transcendentals. Rust's f32::sin / cos / acos call the platform libm (sinf, ...), whose results are within an ulp of,
+// but not always equal to, the correctly rounded value and differ between libms. So that the oracle and the HIP kernels
+// agree bit for bit, both evaluate sin, cos and acos with the same single-precision Cephes kernels (S. Moshier's published
+// sinf.c / asinf.c algorithms: Cody-Waite reduction by pi/4, minimax polynomials), as plain f32 operations in a fixed
+// order; measured error < 2 ulp (tests/test_oracle_kat.py). exp and atan2 (blackbody; sphere uv) go through f64.
+inline float sin32(float xx) {
+    float x = std::fabs(xx);
+    float sign = xx < 0.0f ? -1.0f : 1.0f;
+    int j = (int)(1.27323954473516f * x); // 4/pi
+    float y = (float)j;
+    if (j & 1) {
+        j += 1;
+        y += 1.0f;
+    }
+    j &= 7;
+    if (j > 3) {
+        sign = -sign;
+        j -= 4;
+    }
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    float r;
+    if (j == 1 || j == 2)
+        r = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    else
+        r = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+    return sign * r;
+}
+inline float cos32(float xx) {
+    float x = std::fabs(xx);
+    float sign = 1.0f;
+    int j = (int)(1.27323954473516f * x);
+    float y = (float)j;
+    if (j & 1) {
+        j += 1;
+        y += 1.0f;
+    }
+    j &= 7;
+    if (j > 3) {
+        sign = -sign;
+        j -= 4;
+    }
+    if (j > 1) sign = -sign;
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    float r;
+    if (j == 1 || j == 2)
+        r = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+    else
+        r = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    return sign * r;
+}
+inline float asin32_core(float a) { // asin(a) for 0 <= a <= 1
+    if (a < 1.0e-4f) return a;
+    float x, z;
+    const bool big = a > 0.5f;
+    if (big) {
+        z = 0.5f * (1.0f - a);
+        x = std::sqrt(z);
+    } else {
+        x = a;
+        z = x * x;
+    }
+    float r = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+    if (big) {
+        r = r + r;
+        r = 1.5707963267948966f - r;
+    }
+    return r;
+}
+inline float acos32(float x) {
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asin32_core(std::sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin32_core(std::sqrt(0.5f * (1.0f - x)));
+    float a = asin32_core(std::fabs(x));
+    return 1.5707963267948966f - (x < 0.0f ? -a : a);
+}
 inline float exp32(float x) { return (float)std::exp((double)x); }
 inline float atan2_32(float y, float x) { return (float)std::atan2((double)y, (double)x); }
 
@@ -1847,6 +1916,9 @@ void oracle_sample_cone(uint32_t state[4], const float dir[3], float cos_half, f
     store(r, state);
 }
 float oracle_solid_angle(float cos_half) { return solid_angle(cos_half); }
+float oracle_sin32(float x) { return sin32(x); }
+float oracle_cos32(float x) { return cos32(x); }
+float oracle_acos32(float x) { return acos32(x); }
 float oracle_blackbody(float wavelength, float temperature) { return blackbody(wavelength, temperature); }
 
 int oracle_triangle_intersect(const float v1[3], const float v2[3], const float v3_[3], const float r[6], float* dist, float* u, float* v) {

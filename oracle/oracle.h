@@ -63,6 +63,9 @@ void oracle_sample_sphere(uint32_t state[4], float out[3]);                     
 void oracle_sample_hemisphere(uint32_t state[4], const float dir[3], float out[3]);                /* :155-164 */
 void oracle_sample_cone(uint32_t state[4], const float dir[3], float cos_half, float out[3]);      /* :125-137 */
 float oracle_solid_angle(float cos_half);                                                          /* :139-145 */
+float oracle_sin32(float x); /* the f32 sin / cos / acos kernels both sides use instead of libm (oracle.cpp "Transcendentals") */
+float oracle_cos32(float x);
+float oracle_acos32(float x);
 float oracle_blackbody(float wavelength, float temperature);                                       /* :177-182 */
 
 /* shapes/mod.rs */

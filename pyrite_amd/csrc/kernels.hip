@@ -47,12 +47,83 @@ DEV f3 normalize_to(f3 a, float m) { return a * (m / magnitude(a)); } // cgmath:
 DEV f3 normalize(f3 a) { return normalize_to(a, 1.0f); }
 DEV f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
-// Transcendentals through f64, rounded once: the correctly rounded f32 value (up to ~1e-8 double-rounding cases), the
-// same definition oracle/oracle.cpp uses, so directions agree bit for bit with the CPU restatement. The file is built
-// with -ffp-contract=off for the same reason: the reference (Rust) never fuses a*b+c.
-DEV float sin32(float x) { return (float)sin((double)x); }
-DEV float cos32(float x) { return (float)cos((double)x); }
-DEV float acos32(float x) { return (float)acos((double)x); }
+// Transcendentals. The reference calls the platform libm through Rust's f32::sin / cos / acos; libms differ from one
+// another by an ulp. Here sin, cos and acos are the single-precision Cephes kernels (Moshier; public domain): Cody-Waite
+// reduction by pi/4 in three steps and degree-7/8 minimax polynomials, written as plain f32 operations in a fixed order,
+// the same text as in oracle/oracle.cpp. With -ffp-contract=off both sides round identically, so directions agree bit for
+// bit, and it is ~5x fewer instructions than the OCML routines (which cost 20 % of the C2 render). Accuracy: < 2 ulp on
+// [-2 pi, 2 pi] for sin/cos and on [-1, 1] for acos (tests/test_oracle_kat.py). exp (blackbody only) goes through f64.
+DEV float sin32(float xx) {
+    float x = fabsf(xx);
+    float sign = xx < 0.0f ? -1.0f : 1.0f;
+    int j = (int)(1.27323954473516f * x); // 4/pi
+    float y = (float)j;
+    if (j & 1) {
+        j += 1;
+        y += 1.0f;
+    }
+    j &= 7;
+    if (j > 3) {
+        sign = -sign;
+        j -= 4;
+    }
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    float r;
+    if (j == 1 || j == 2)
+        r = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    else
+        r = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+    return sign * r;
+}
+DEV float cos32(float xx) {
+    float x = fabsf(xx);
+    float sign = 1.0f;
+    int j = (int)(1.27323954473516f * x);
+    float y = (float)j;
+    if (j & 1) {
+        j += 1;
+        y += 1.0f;
+    }
+    j &= 7;
+    if (j > 3) {
+        sign = -sign;
+        j -= 4;
+    }
+    if (j > 1) sign = -sign;
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    float r;
+    if (j == 1 || j == 2)
+        r = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+    else
+        r = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    return sign * r;
+}
+DEV float asin32_core(float a) { // asin(a) for 0 <= a <= 1
+    if (a < 1.0e-4f) return a;
+    float x, z;
+    const bool big = a > 0.5f;
+    if (big) {
+        z = 0.5f * (1.0f - a);
+        x = sqrtf(z);
+    } else {
+        x = a;
+        z = x * x;
+    }
+    float r = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+    if (big) {
+        r = r + r;
+        r = 1.5707963267948966f - r;
+    }
+    return r;
+}
+DEV float acos32(float x) {
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asin32_core(sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin32_core(sqrtf(0.5f * (1.0f - x)));
+    float a = asin32_core(fabsf(x));
+    return 1.5707963267948966f - (x < 0.0f ? -a : a);
+}
 DEV float exp32(float x) { return (float)exp((double)x); }
 
 // ------------------------------------------------------------------------------------------------ RNG
@@ -343,6 +414,81 @@ DEV float run_program(const DevScene& S, uint32_t id, const VmInput& in) {
     case FAST_MUL_SPECTRUM: return p.fast_scale * spectrum_get(S, p.fast_spectrum, in.wavelength);
     default:
         if constexpr (INTERP) return run_interpreter(S, p, in);
+        return 0.0f;
+    }
+}
+
+// A colour program is evaluated for the hero wavelength and then for each companion: `prepare_program` pulls the program
+// record and (for the fast shapes) the spectrum record into registers once, `eval_prepared` is then the arithmetic of
+// Spectrum::get alone -- the same operations as spectrum_get / run_program, so the values are identical.
+struct Prepared {
+    uint32_t mode; // 0 constant, FAST_* for the fast shapes, 0xFF interpreter
+    float c;       // the constant / the scale
+    PyrSpectrum sp;
+    const float* data;
+    uint32_t id;
+};
+template <bool INTERP>
+DEV Prepared prepare_program(const DevScene& S, uint32_t id) {
+    Prepared q{};
+    q.id = id;
+    const DevProgram* p = S.programs + id;
+    if (p->kind == PYR_PROGRAM_CONSTANT) {
+        q.mode = 0;
+        q.c = p->constant;
+        return q;
+    }
+    const uint32_t fast = p->fast;
+    if (fast == FAST_NONE) {
+        q.mode = 0xFFu;
+        return q;
+    }
+    q.mode = fast;
+    q.c = p->fast_scale;
+    q.sp = S.spectra[p->fast_spectrum];
+    q.data = S.spectrum_data + q.sp.offset;
+    return q;
+}
+DEV float spectrum_eval(const PyrSpectrum& sp, const float* data, float w) { // == spectrum_get with the record in registers
+    if (sp.format == PYR_SPECTRUM_ARRAY) {
+        if (sp.count == 0) return 0.0f;
+        if (w <= sp.min) return data[0];
+        if (w >= sp.max) return data[sp.count - 1];
+        float normalized = (w - sp.min) / (sp.max - sp.min);
+        float float_index = normalized * ((float)sp.count - 1.0f);
+        float min_float_index = truncf(float_index);
+        uint32_t i0 = (uint32_t)min_float_index;
+        float mix = float_index - min_float_index;
+        return data[i0] * (1.0f - mix) + data[i0 + 1] * mix;
+    }
+    uint32_t count = sp.count;
+    if (count == 0) return 0.0f;
+    uint32_t mn = 0, mx = count - 1;
+    if (data[2 * mn] >= w) return 0.0f;
+    if (data[2 * mx] <= w) return 0.0f;
+    while (mx > mn + 1) {
+        uint32_t check = (mx + mn) / 2;
+        float cx = data[2 * check];
+        if (cx == w) return data[2 * check + 1];
+        if (cx > w)
+            mx = check;
+        else
+            mn = check;
+    }
+    float min_x = data[2 * mn], min_y = data[2 * mn + 1];
+    float max_x = data[2 * mx], max_y = data[2 * mx + 1];
+    if (w < min_x || w > max_x) return 0.0f;
+    return min_y + (max_y - min_y) * ((w - min_x) / (max_x - min_x));
+}
+template <bool INTERP>
+DEV float eval_prepared(const DevScene& S, const Prepared& q, const VmInput& in) {
+    switch (q.mode) {
+    case 0: return q.c;
+    case FAST_SPECTRUM: return spectrum_eval(q.sp, q.data, in.wavelength);
+    case FAST_SPECTRUM_MUL: return spectrum_eval(q.sp, q.data, in.wavelength) * q.c;
+    case FAST_MUL_SPECTRUM: return q.c * spectrum_eval(q.sp, q.data, in.wavelength);
+    default:
+        if constexpr (INTERP) return run_interpreter(S, S.programs[q.id], in);
         return 0.0f;
     }
 }
@@ -902,12 +1048,13 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                 }
             }
         }
+        const Prepared q_prog = prepare_program<INTERP>(S, color);
         VmInput in{p.wl, -ray_d, ray_d};
-        p.bright += run_program<INTERP>(S, color, in) * 1.0f * p.refl;
+        p.bright += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * p.refl;
         if (p.use_additional)
             for (uint32_t k = 0; k < n_add; ++k) {
                 in.wavelength = spec.wl(k);
-                spec.bright(k) += run_program<INTERP>(S, color, in) * 1.0f * spec.refl(k);
+                spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * spec.refl(k);
             }
         return true;
     }
@@ -930,12 +1077,13 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
     if (comp.bsdf == PYR_BSDF_EMISSIVE) { // Scattering::Emitted, tracer.rs:303-318
         if (p.sample_light) {
             p.use_additional = !normal_dispersed && p.use_additional;
+            const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
             VmInput in{p.wl, normal, ray_d};
-            p.bright += run_program<INTERP>(S, comp.color_program, in) * component_probability * p.refl;
+            p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
             if (p.use_additional)
                 for (uint32_t k = 0; k < n_add; ++k) {
                     in.wavelength = spec.wl(k);
-                    spec.bright(k) += run_program<INTERP>(S, comp.color_program, in) * component_probability * spec.refl(k);
+                    spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * component_probability * spec.refl(k);
                 }
         }
         return true;
@@ -968,12 +1116,13 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
     const float bounce_probability = scatter_probability * component_probability; // tracer.rs:296
     p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;       // simple.rs:122-123, tracer.rs:290
     {
+        const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
         VmInput in{p.wl, normal, ray_d};
-        p.refl *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+        p.refl *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
         if (p.use_additional)
             for (uint32_t k = 0; k < n_add; ++k) {
                 in.wavelength = spec.wl(k);
-                spec.refl(k) *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+                spec.refl(k) *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
             }
     }
 
@@ -1016,12 +1165,13 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                     const float scale = ls.weight * probability * (2.0f * fabsf(dot(ls.direction, nff))); // lambertian, diffuse.rs:27-29
                     const float l_probability = scale * material_probability;
                     // contribute, direct light (algorithm.rs:65-90)
+                    const Prepared q_prog = prepare_program<INTERP>(S, l_color);
                     VmInput in{p.wl, target_normal, ls.direction};
-                    p.bright += run_program<INTERP>(S, l_color, in) * l_probability * p.refl;
+                    p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
                     if (p.use_additional && !l_dispersed)
                         for (uint32_t k = 0; k < n_add; ++k) {
                             in.wavelength = spec.wl(k);
-                            spec.bright(k) += run_program<INTERP>(S, l_color, in) * l_probability * spec.refl(k);
+                            spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
                         }
                 }
             }
@@ -1437,12 +1587,13 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
                             }
                         }
                     }
+                    const Prepared q_prog = prepare_program<INTERP>(S, color);
                     VmInput in{p.wl, -ray_d, ray_d};
-                    p.bright += run_program<INTERP>(S, color, in) * 1.0f * p.refl;
+                    p.bright += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * p.refl;
                     if (p.use_additional)
                         for (uint32_t k = 0; k < n_add; ++k) {
                             in.wavelength = spec.wl(k);
-                            spec.bright(k) += run_program<INTERP>(S, color, in) * 1.0f * spec.refl(k);
+                            spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * spec.refl(k);
                         }
                     stage = ST_EXPOSE;
                 } else {
@@ -1464,12 +1615,13 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
                     if (comp.bsdf == PYR_BSDF_EMISSIVE) {
                         if (p.sample_light) {
                             p.use_additional = !normal_dispersed && p.use_additional;
+                            const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
                             VmInput in{p.wl, normal, ray_d};
-                            p.bright += run_program<INTERP>(S, comp.color_program, in) * component_probability * p.refl;
+                            p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
                             if (p.use_additional)
                                 for (uint32_t k = 0; k < n_add; ++k) {
                                     in.wavelength = spec.wl(k);
-                                    spec.bright(k) += run_program<INTERP>(S, comp.color_program, in) * component_probability * spec.refl(k);
+                                    spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * component_probability * spec.refl(k);
                                 }
                         }
                         stage = ST_EXPOSE;
@@ -1498,12 +1650,13 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
                         const float bounce_probability = scatter_probability * component_probability;
                         p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
                         {
+                            const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
                             VmInput in{p.wl, normal, ray_d};
-                            p.refl *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+                            p.refl *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
                             if (p.use_additional)
                                 for (uint32_t k = 0; k < n_add; ++k) {
                                     in.wavelength = spec.wl(k);
-                                    spec.refl(k) *= run_program<INTERP>(S, comp.color_program, in) * bounce_probability;
+                                    spec.refl(k) *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
                                 }
                         }
                         b_position = position;
@@ -1562,12 +1715,13 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
                             target_normal = ls_normal;
                         }
                         const float l_probability = ls_scale * material_probability;
+                        const Prepared q_prog = prepare_program<INTERP>(S, l_color);
                         VmInput in{p.wl, target_normal, t.d};
-                        p.bright += run_program<INTERP>(S, l_color, in) * l_probability * p.refl;
+                        p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
                         if (p.use_additional && !l_dispersed)
                             for (uint32_t k = 0; k < n_add; ++k) {
                                 in.wavelength = spec.wl(k);
-                                spec.bright(k) += run_program<INTERP>(S, l_color, in) * l_probability * spec.refl(k);
+                                spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
                             }
                     }
                 }

@@ -56,6 +56,9 @@ def lib():
         L.oracle_sample_cone.argtypes = [U4, F3, C.c_float, F3]
         L.oracle_solid_angle.argtypes = [C.c_float]
         L.oracle_solid_angle.restype = C.c_float
+        for name in ("oracle_sin32", "oracle_cos32", "oracle_acos32"):
+            getattr(L, name).argtypes = [C.c_float]
+            getattr(L, name).restype = C.c_float
         L.oracle_blackbody.argtypes = [C.c_float, C.c_float]
         L.oracle_blackbody.restype = C.c_float
         L.oracle_triangle_intersect.argtypes = [F3, F3, F3, F6, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -322,3 +322,21 @@ def test_pinhole_camera_ray():
     L.oracle_ray_towards(C.byref(cam), st, 0.0, 0.0, r6)
     assert list(st) != before  # thin lens draws two numbers
     assert (r6[0] - 3) ** 2 + (r6[1] - 4) ** 2 <= 0.02 + 1e-6  # lens radius^2 = aperture * u
+
+
+def test_trig_kernels_are_within_two_ulp():
+    # sin / cos / acos are evaluated by fixed f32 polynomial kernels on both sides (oracle.cpp "Transcendentals");
+    # they must stay within 2 ulp of the correctly rounded value over the ranges the renderer uses.
+    def max_ulp(f, ref, xs):
+        out = np.array([f(float(x)) for x in xs], dtype=np.float64)
+        exact = ref(xs.astype(np.float64))
+        ulp = np.spacing(np.abs(exact.astype(f32))).astype(np.float64)
+        return float(np.max(np.abs(out - exact) / ulp))
+
+    rng = np.random.RandomState(1)
+    angles = rng.uniform(0, 2 * math.pi, 20000).astype(f32)
+    assert max_ulp(L.oracle_sin32, np.sin, angles) < 2.0
+    assert max_ulp(L.oracle_cos32, np.cos, angles) < 2.0
+    assert max_ulp(L.oracle_acos32, np.arccos, rng.uniform(-1, 1, 20000).astype(f32)) < 2.0
+    assert (L.oracle_sin32(0.0), L.oracle_cos32(0.0), L.oracle_acos32(1.0)) == (0.0, 1.0, 0.0)
+    assert L.oracle_acos32(-1.0) == f32(math.pi) and L.oracle_acos32(0.0) == f32(math.pi / 2)
