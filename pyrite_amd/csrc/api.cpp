@@ -180,12 +180,8 @@ struct PyrScene {
         spectrum_data, rgb_basis, counters;
     PyrCounters last_counters{};
     bool have_counters = false;
-    // tail queue (kernels.hip): grown on demand, reused by every render on this scene
-    void* tail_queue = nullptr;
-    uint32_t* tail_count = nullptr;
-    uint32_t tail_capacity = 0, tail_fields = 0;
+    uint32_t* tail_count = nullptr; // device word: the ray-batch cursor of the intersect kernel
     ~PyrScene() {
-        if (tail_queue) (void)hipFree(tail_queue);
         if (tail_count) (void)hipFree(tail_count);
     }
 };
@@ -403,52 +399,24 @@ int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
     return PYR_OK;
 }
 
-// Bounces the head kernel walks before it parks a path for the tail kernel. 0xFFFFFFFF = the head walks every bounce (no
-// tail). Measured on C2 (MI355X): parking after the two NEE bounces is 0.93x the speed of the plain bounce-synchronous
-// walk, so the split is off by default; PYRITE_HEAD_BOUNCES=n turns it on for experiments (deep-bounce scenes).
-static uint32_t head_bounces_setting() {
-    const char* e = std::getenv("PYRITE_HEAD_BOUNCES");
-    if (e && *e) return (uint32_t)std::strtoul(e, nullptr, 10);
-    return 0xFFFFFFFFu;
-}
-constexpr uint32_t kMaxBatchPaths = 1u << 24; // samples per head/tail launch pair
-
-// Runs [L.chunk_begin, L.chunk_end) as head + tail launch pairs, each small enough for the tail queue.
+// Scheduler choice (kernels.hip): the bounce-synchronous walk wins when the scene lives in LDS and traversal is cheap
+// (C2: 573 vs 300 Msamples/s); the stage scheduler wins when traversal lengths are heavy tailed (C3: 110 vs 91).
+// PYRITE_SCHEDULER=sync|sm overrides; PYRITE_SM_LANES / PYRITE_SM_STEPS tune the stage scheduler.
 int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stream) {
-    const uint32_t total_chunks = L.chunk_end - L.chunk_begin;
-    if (total_chunks == 0) return PYR_OK;
-    L.head_bounces = head_bounces_setting();
-    {
-        const char* e = std::getenv("PYRITE_SCHEDULER"); // "sync" | "sm"
-        L.scheduler = (e && std::string(e) == "sm") ? 1u : 0u;
-        const char* lanes = std::getenv("PYRITE_SM_LANES");
-        const char* steps = std::getenv("PYRITE_SM_STEPS");
-        L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
-        L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
-    }
-    const uint32_t fields = tail_queue_fields(L.spectrum_samples);
-    const uint64_t want = std::min<uint64_t>((uint64_t)total_chunks * 64, kMaxBatchPaths);
-    if (L.bounces > L.head_bounces && (scene->tail_capacity < want || scene->tail_fields != fields)) {
-        if (scene->tail_queue) HIP_TRY(hipFree(scene->tail_queue));
-        scene->tail_queue = nullptr;
-        scene->tail_capacity = 0;
-        HIP_TRY(hipMalloc(&scene->tail_queue, (size_t)want * fields * sizeof(float)));
-        scene->tail_capacity = (uint32_t)want;
-        scene->tail_fields = fields;
-    }
-    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, sizeof(uint32_t)));
-    L.tail_queue = (float*)scene->tail_queue;
-    L.tail_count = scene->tail_count;
-    L.tail_capacity = scene->tail_capacity;
-    const uint32_t batch_chunks = std::max<uint32_t>(1, (uint32_t)(want / 64));
-    const uint32_t first = L.chunk_begin, last = L.chunk_end;
-    for (uint32_t begin = first; begin < last; begin += batch_chunks) {
-        L.chunk_begin = begin;
-        L.chunk_end = std::min(last, begin + batch_chunks);
-        HIP_TRY(hipMemsetAsync(scene->tail_count, 0, sizeof(uint32_t), stream));
-        int rc = launch_render(scene->dev, L, count, stream, scene->num_cus);
-        if (rc != PYR_OK) return fail(rc, kernels_last_error());
-    }
+    if (L.chunk_end == L.chunk_begin) return PYR_OK;
+    const char* e = std::getenv("PYRITE_SCHEDULER");
+    if (e && std::string(e) == "sm")
+        L.scheduler = 1;
+    else if (e && std::string(e) == "sync")
+        L.scheduler = 0;
+    else
+        L.scheduler = scene_is_lds_resident(scene->dev) ? 0u : 1u;
+    const char* lanes = std::getenv("PYRITE_SM_LANES");
+    const char* steps = std::getenv("PYRITE_SM_STEPS");
+    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
+    L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
+    int rc = launch_render(scene->dev, L, count, stream, scene->num_cus);
+    if (rc != PYR_OK) return fail(rc, kernels_last_error());
     return PYR_OK;
 }
 

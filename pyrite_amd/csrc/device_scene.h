@@ -93,14 +93,8 @@ struct RenderLaunch {
     float grains_per_wavelength; // bins / wl_width (film.rs:38)
     PyrGrain* film_out;
     unsigned long long* counters; // 9 words (PyrCounters order) or nullptr
-    // Tail queue (kernels.hip): paths alive after `head_bounces` bounces are parked in `tail_queue`
-    // ([tail_queue_fields(S)][tail_capacity] floats) and finished by the tail kernel; *tail_count is zero at launch.
-    uint32_t scheduler; // 0 = bounce-synchronous head (+ optional tail), 1 = stage-scheduled state machine
+    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm)
     uint32_t sm_phase_lanes, sm_trav_steps; // stage scheduler: lanes that make a phase run; traversal steps per turn
-    uint32_t head_bounces;
-    uint32_t tail_capacity;
-    float* tail_queue;
-    uint32_t* tail_count;
 };
 
 struct IntersectLaunch {
@@ -117,6 +111,6 @@ struct IntersectLaunch {
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);
 const char* kernels_last_error();
-uint32_t tail_queue_fields(uint32_t spectrum_samples);
+bool scene_is_lds_resident(const DevScene& scene);
 
 } // namespace pyr

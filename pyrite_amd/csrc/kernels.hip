@@ -1201,54 +1201,12 @@ DEV void finish_path(const RenderLaunch& L, const Path& p, Spectral& spec, Count
         for (uint32_t k = 0; k + 1 < L.spectrum_samples; ++k) expose_grain<COUNT>(L, pixel_base, spec.wl(k), spec.bright(k), cnt);
 }
 
-// ---- the tail queue: paths that survive the head's bounces, parked in HBM as structure-of-arrays [field][slot]
-constexpr uint32_t kTailScalarFields = 17; // rng 4, px py 2, o 3, d 3, wl bright refl 3, bounce, events|flags
-DEV uint32_t tail_fields(uint32_t spectrum_samples) { return kTailScalarFields + 3 * (spectrum_samples - 1); }
-
-DEV void tail_store(float* q, uint32_t cap, uint32_t slot, const Path& p, Spectral& spec, uint32_t SS) {
-    float* f = q + slot;
-    auto put = [&](uint32_t field, float v) { f[(size_t)field * cap] = v; };
-    put(0, __uint_as_float(p.rng.x));
-    put(1, __uint_as_float(p.rng.y));
-    put(2, __uint_as_float(p.rng.z));
-    put(3, __uint_as_float(p.rng.w));
-    put(4, p.px);
-    put(5, p.py);
-    put(6, p.o.x), put(7, p.o.y), put(8, p.o.z);
-    put(9, p.d.x), put(10, p.d.y), put(11, p.d.z);
-    put(12, p.wl), put(13, p.bright), put(14, p.refl);
-    put(15, __uint_as_float(p.bounce));
-    put(16, __uint_as_float(p.events | (p.use_additional ? 4u : 0u) | (p.sample_light ? 8u : 0u)));
-    for (uint32_t k = 0; k + 1 < SS; ++k) {
-        put(kTailScalarFields + 3 * k + 0, spec.wl(k));
-        put(kTailScalarFields + 3 * k + 1, spec.bright(k));
-        put(kTailScalarFields + 3 * k + 2, spec.refl(k));
-    }
-}
-DEV void tail_load(const float* q, uint32_t cap, uint32_t slot, Path& p, Spectral& spec, uint32_t SS) {
-    const float* f = q + slot;
-    auto get = [&](uint32_t field) { return f[(size_t)field * cap]; };
-    p.rng = Rng{__float_as_uint(get(0)), __float_as_uint(get(1)), __float_as_uint(get(2)), __float_as_uint(get(3))};
-    p.px = get(4), p.py = get(5);
-    p.o = mk(get(6), get(7), get(8));
-    p.d = mk(get(9), get(10), get(11));
-    p.wl = get(12), p.bright = get(13), p.refl = get(14);
-    p.bounce = __float_as_uint(get(15));
-    uint32_t packed = __float_as_uint(get(16));
-    p.events = packed & 3u;
-    p.use_additional = (packed & 4u) != 0;
-    p.sample_light = (packed & 8u) != 0;
-    for (uint32_t k = 0; k + 1 < SS; ++k) {
-        spec.wl(k) = get(kTailScalarFields + 3 * k + 0);
-        spec.bright(k) = get(kTailScalarFields + 3 * k + 1);
-        spec.refl(k) = get(kTailScalarFields + 3 * k + 2);
-    }
-}
-
-// HEAD kernel: sample generation and the first `head_bounces` bounces, walked bounce-synchronously by the wave -- that
-// is where next-event estimation happens (first two diffuse events, tracer.rs:257), and all 64 lanes want it at the same
-// time. Paths that are still alive afterwards are compacted into the tail queue (one wave-aggregated atomic per wave:
-// ballot + prefix count give each surviving lane its slot); the rest expose their spectra.
+// Bounce-synchronous integrator: a wave takes a chunk of 64 samples and walks the 64 paths bounce by bounce. Next-event
+// estimation happens in the first two diffuse events of a path (tracer.rs:257), i.e. at the same time for all 64 lanes
+// of a diffuse scene, which is why this plain walk beats per-lane refill on C2:
+//   * refilling a lane as soon as its path ends (one bounce per loop turn)                         0.60x
+//   * parking survivors of the first two bounces in a ballot-compacted HBM queue for a tail kernel  0.93x
+// (MI355X, C2, 64 spp; both were built and measured, see DESIGN.md "Scheduling experiments").
 template <bool COUNT, bool INTERP, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
@@ -1264,92 +1222,22 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
     const uint32_t waves_per_block = BLOCK / 64;
     const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t total_waves = gridDim.x * waves_per_block;
-    const uint32_t head_bounces = min(L.bounces, L.head_bounces);
 
     for (uint32_t chunk = L.chunk_begin + wave; chunk < L.chunk_end; chunk += total_waves) {
         uint32_t tile;
         uint64_t iteration;
         TileArea area;
-        bool alive = locate_chunk(L, chunk, lane, tile, iteration, area);
+        if (!locate_chunk(L, chunk, lane, tile, iteration, area)) continue;
         Path p{};
-        if (alive) {
-            start_sample(L, tile, iteration, area, p, spec);
-            if (COUNT) cnt.samples++;
-        }
-        const bool started = alive;
-        while (alive && p.bounce < head_bounces) {
+        start_sample(L, tile, iteration, area, p, spec);
+        if (COUNT) cnt.samples++;
+        while (p.bounce < L.bounces) {
             const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt);
             p.bounce++;
-            if (ended) alive = false;
+            if (ended) break;
         }
-        const bool to_tail = alive && p.bounce < L.bounces;
-        // wave-level compaction of the survivors into the tail queue
-        const unsigned long long mask = __ballot(to_tail);
-        if (mask != 0) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(L.tail_count, (uint32_t)__popcll(mask));
-            base = __shfl(base, 0, 64);
-            if (to_tail) {
-                uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                tail_store(L.tail_queue, L.tail_capacity, slot, p, spec, SS);
-            }
-        }
-        if (started && !to_tail) finish_path<COUNT>(L, p, spec, cnt);
+        finish_path<COUNT>(L, p, spec, cnt);
     }
-    flush_counters<COUNT>(cnt, L.counters);
-}
-
-// TAIL kernel: the remaining bounces of the parked paths. No lane waits for another path here: a lane whose path ends
-// exposes it and pulls the next parked path at once (strided slots), so occupancy stays full while path lengths differ.
-template <bool COUNT, bool INTERP, bool LDS_SCENE>
-__global__ __launch_bounds__(BLOCK, 4) void tail_kernel(DevScene S0, RenderLaunch L) {
-    extern __shared__ float lds[];
-    const uint32_t SS = L.spectrum_samples;
-    Spectral spec{lds + threadIdx.x, SS};
-    int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
-    Counters cnt{};
-    const uint32_t lds_base_floats = (3 * SS + S0.stack_depth) * BLOCK;
-    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
-    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
-
-    const uint32_t count = *L.tail_count;
-    const uint32_t stride = gridDim.x * BLOCK;
-    uint32_t next = blockIdx.x * BLOCK + threadIdx.x;
-    // Lane states: alive (has a path to advance), pending (its path ended and still has to be exposed), exhausted (no parked
-    // path left for it). Exposing a path and loading the next one are "service" work that only a few lanes need per
-    // iteration; run for one lane it costs the whole wave. So ended lanes wait until kServiceLanes of them have piled up
-    // (or nothing else is left to do) and are then serviced together.
-    constexpr int kServiceLanes = 16;
-    bool alive = false, pending = false, exhausted = false;
-    Path p{};
-    for (;;) {
-        const int idle = __popcll(__ballot(!alive));
-        if (idle >= kServiceLanes || idle == 64) {
-            if (!alive) {
-                if (pending) {
-                    finish_path<COUNT>(L, p, spec, cnt);
-                    pending = false;
-                }
-                if (next < count) {
-                    tail_load(L.tail_queue, L.tail_capacity, next, p, spec, SS);
-                    next += stride;
-                    alive = true;
-                } else {
-                    exhausted = true;
-                }
-            }
-            if (__ballot(alive) == 0) break; // every lane exhausted and nothing pending
-        }
-        if (alive) {
-            const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt);
-            p.bounce++;
-            if (ended || p.bounce >= L.bounces) {
-                alive = false;
-                pending = true;
-            }
-        }
-    }
-    (void)exhausted;
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -1831,26 +1719,19 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
     return bytes;
 }
 
-uint32_t tail_queue_fields(uint32_t spectrum_samples) { return kTailScalarFields + 3 * (spectrum_samples - 1); }
-
 using RenderKernel = void (*)(DevScene, RenderLaunch);
-static RenderKernel pick_sm_kernel(bool with_counters, bool interp, bool lds_scene) {
-    static const RenderKernel sm[2][2][2] = {
-        {{render_kernel_sm<false, false, false>, render_kernel_sm<false, false, true>}, {render_kernel_sm<false, true, false>, render_kernel_sm<false, true, true>}},
-        {{render_kernel_sm<true, false, false>, render_kernel_sm<true, false, true>}, {render_kernel_sm<true, true, false>, render_kernel_sm<true, true, true>}}};
-    return sm[with_counters ? 1 : 0][interp ? 1 : 0][lds_scene ? 1 : 0];
-}
-static RenderKernel pick_kernel(bool tail, bool with_counters, bool interp, bool lds_scene) {
-    static const RenderKernel head[2][2][2] = {
+static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene) {
+    static const RenderKernel sync[2][2][2] = {
         {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
         {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
-    static const RenderKernel tails[2][2][2] = {
-        {{tail_kernel<false, false, false>, tail_kernel<false, false, true>}, {tail_kernel<false, true, false>, tail_kernel<false, true, true>}},
-        {{tail_kernel<true, false, false>, tail_kernel<true, false, true>}, {tail_kernel<true, true, false>, tail_kernel<true, true, true>}}};
-    return (tail ? tails : head)[with_counters ? 1 : 0][interp ? 1 : 0][lds_scene ? 1 : 0];
+    static const RenderKernel staged[2][2][2] = {
+        {{render_kernel_sm<false, false, false>, render_kernel_sm<false, false, true>}, {render_kernel_sm<false, true, false>, render_kernel_sm<false, true, true>}},
+        {{render_kernel_sm<true, false, false>, render_kernel_sm<true, false, true>}, {render_kernel_sm<true, true, false>, render_kernel_sm<true, true, true>}}};
+    return (sm ? staged : sync)[with_counters ? 1 : 0][interp ? 1 : 0][lds_scene ? 1 : 0];
 }
 
-// Launches the head kernel over [chunk_begin, chunk_end) and then the tail kernel over whatever the head parked.
+bool scene_is_lds_resident(const DevScene& scene) { return scene_fits_lds(scene); }
+
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus) {
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
@@ -1859,37 +1740,30 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
     }
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
-    for (int tail = 0; tail < 2; ++tail) {
-        RenderKernel kernel = launch.scheduler == 1 ? pick_sm_kernel(with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene))
-                                                    : pick_kernel(tail != 0, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene));
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) {
-            g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
-            return PYR_ERR_DEVICE;
-        }
-        // Residency of a 256-thread block (one wave per SIMD): waves per SIMD allowed by the 512-entry register file
-        // (8-register granules, MI355X_MICROARCH.md "Register files") and by the 160 KB of LDS. The grids are persistent but
-        // need no co-residency (no inter-block hand-off), so an over-estimate only queues blocks.
-        hipFuncAttributes attr{};
-        int blocks_per_cu = 4;
-        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) == hipSuccess && attr.numRegs > 0) {
-            int regs = ((attr.numRegs + 7) / 8) * 8;
-            blocks_per_cu = std::min(8, 512 / regs);
-        }
-        blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
-        uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
-        if (tail == 0) {
-            uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
-            if (grid > blocks_needed) grid = blocks_needed;
-        } else if (launch.scheduler == 1 || launch.head_bounces >= launch.bounces) {
-            break; // no tail launch: the stage scheduler / the head walks every bounce
-        }
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
-        err = hipGetLastError();
-        if (err != hipSuccess) {
-            g_kernel_error = std::string("render kernel launch: ") + hipGetErrorString(err);
-            return PYR_ERR_DEVICE;
-        }
+    RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene));
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    // Residency of a 256-thread block (one wave per SIMD): waves per SIMD allowed by the 512-entry register file
+    // (8-register granules, MI355X_MICROARCH.md "Register files") and by the 160 KB of LDS. The grid is persistent but needs
+    // no co-residency (no inter-block hand-off), so an over-estimate only queues blocks.
+    hipFuncAttributes attr{};
+    int blocks_per_cu = 4;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) == hipSuccess && attr.numRegs > 0) {
+        int regs = ((attr.numRegs + 7) / 8) * 8;
+        blocks_per_cu = std::min(8, 512 / regs);
+    }
+    blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
+    uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
+    uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
+    if (grid > blocks_needed) grid = blocks_needed;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("render kernel launch: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
     }
     return PYR_OK;
 }

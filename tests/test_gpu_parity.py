@@ -85,6 +85,18 @@ def test_render_matches_the_oracle(name, gpu_lib):
         assert gcount[key] == ccount[key], key
 
 
+@pytest.mark.parametrize("scheduler", ["sync", "sm"])
+@pytest.mark.parametrize("name", ["c2_cornell", "lamps_example", "diamonds_example"])
+def test_both_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypatch):
+    """The bounce-synchronous walk and the stage-scheduled state machine are two schedules of the same per-path work: both
+    must reproduce the oracle (the library picks one per scene; PYRITE_SCHEDULER forces it)."""
+    monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
+    gfilm, cfilm, gcount, ccount = render_both(CASES[name](), 8, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+
+
 def test_ragged_image_and_odd_parameters(gpu_lib):
     project = scenes.c2_cornell(50, 37, 3)  # tiles of 16: ragged right column and bottom row
     project["renderer"] = renderer.simple(pixel_samples=3, tile_size=16, spectrum_samples=7, light_samples=1, bounces=3)
