@@ -75,6 +75,39 @@ def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
     }
 
 
+def traversal_roofline(device_index, n_rays=16_000_000):
+    """World::intersect alone (pyr_scene_intersect: persistent waves, dynamic ray fetch) on the C3 scene -- the
+    819,212-triangle mesh in the x10 Cornell box -- with incoherent rays (uniform origins in the box, uniform directions).
+    This is north_star's "HBM-read roofline on BVH traversal": algorithmic bytes = 32 B per box test + 36 B per triangle
+    test (counted by the instrumented build on the same batch), over the kernel time from HIP events."""
+    import numpy as np
+
+    from pyrite_amd import scenes
+
+    world, _, _, _ = scenes.build(scenes.c3_mesh_in_box(64, 36, 1), seed=1)
+    rng = np.random.RandomState(1)
+    o = rng.uniform([-55, 1, 1], [-1, 55, 54], size=(n_rays, 3))
+    d = rng.normal(size=(n_rays, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    _, _, counters = world.intersect(rays, device=device_index, want_counters=True)
+    best = None
+    for _ in range(3):
+        _, ms, _ = world.intersect(rays, device=device_index)
+        best = ms if best is None else min(best, ms)
+    nbytes = 32 * counters["box_tests"] + 36 * counters["triangle_tests"]
+    achieved = nbytes / (best * 1e-3) / 1e9
+    info = world.bvh_info(device_index)
+    world.close()
+    return {
+        "kernel": "intersect_kernel<false>", "scene": "C3 mesh (819,212 triangles, %d nodes of 64 B)" % info["num_nodes"],
+        "rays": n_rays, "ray_kind": "incoherent (uniform origins and directions)", "kernel_ms": round(best, 3),
+        "Mrays_per_s": round(n_rays / best / 1e3, 1), "box_tests_per_ray": round(counters["box_tests"] / n_rays, 2),
+        "triangle_tests_per_ray": round(counters["triangle_tests"] / n_rays, 2), "bound": "hbm", "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+    }
+
+
 def load_traffic(workload):
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
@@ -94,6 +127,7 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (development only: the line is then marked reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traversal", action="store_true", help="skip the BVH-traversal roofline measurement on the C3 scene")
     ap.add_argument("--dev", default="", help="development overrides, e.g. spectrum_samples=1,light_samples=0,bounces=2 (marks the line reduced)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -204,6 +238,11 @@ def main():
         torch.cuda.synchronize(device)
         counters = renderer.counters(world, local_rank)
         del window
+        info = world.bvh_info(local_rank)
+        lds_resident = info["node_bytes"] + info["primitive_bytes"] <= 8 * 1024
+        forced = os.environ.get("PYRITE_SCHEDULER")
+        staged = forced == "sm" or (forced != "sync" and not lds_resident)
+        kernel_name = "render_kernel_sm (stage-scheduled)" if staged else "render_kernel (bounce-synchronous)"
         traversal = 32 * counters["box_tests"] + 36 * counters["triangle_tests"] + 16 * (counters["sphere_tests"] + counters["plane_tests"])
         total = algorithmic_bytes(counters)
         achieved = total / (kernel_ms * 1e-3) / 1e9
@@ -214,13 +253,15 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": load_traffic(args.workload),
-            "kernel": "render_kernel<false>",
+            "kernel": kernel_name,
             "kernel_ms": round(kernel_ms, 3),
             "algorithmic_bytes_per_launch": int(total),
             "traversal_bytes_per_launch": int(traversal),
             "traversal_frac": round(traversal / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "counters": counters,
         }
+        if not args.no_traversal:
+            line["traversal_roofline"] = traversal_roofline(local_rank)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(world, cam, renderer, width, height)
     if rank == 0:
