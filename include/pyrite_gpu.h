@@ -348,6 +348,34 @@ typedef struct PyrBvhInfo {
 } PyrBvhInfo;
 int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out);
 
+/* ---------------------------------------------------------------- film development ("next" row f1) -------------
+ * The step after the hot path: main.rs:315-327 turns every developed pixel spectrum into an 8-bit sRGB pixel through
+ * spectrum_to_xyz (main.rs:352-369: trapezoid rule over the film's wavelength span in `step_size` steps against the
+ * CIE 1931 observer tables, divided by the span, times 3.444) and palette's Xyz -> linear sRGB -> sRGB encoding.
+ * The optional `filter` and `white` programs of the project's image settings (main.rs:197-238) act on the sampled
+ * intensity as  ((intensity * filter[i]) / white_div[i]) * white_mul[i]  at the i-th sampling wavelength
+ * wl_i = wl_start + i*step_size (i = 0 .. sample_count-1); the host evaluates those programs once per wavelength and
+ * passes the three arrays (NULL = stage absent).
+ * As in the reference, the LAST pixel of the film is never developed (film.rs:299 `end < len`) and stays black. */
+typedef struct PyrDevelopParams {
+    float step_size;         /* 2.0 for the final image, 30.0 for previews (main.rs:270, :311) */
+    float xyz_scale;         /* 3.444 (main.rs:368) */
+    uint32_t sample_count;   /* number of sampling wavelengths = trapezoid steps + 1 */
+    const float* filter;     /* [sample_count] or NULL */
+    const float* white_div;  /* [sample_count] or NULL: max(white(wl)/white_max, 1e-6) */
+    const float* white_mul;  /* [sample_count] or NULL: D65(wl)/D65_max */
+    const float* xyz_table;  /* [xyz_count][3]: crate::xyz::response::{X,Y,Z} (build.rs:68-121), ARRAY spectra over [xyz_min, xyz_max] */
+    uint32_t xyz_count;
+    float xyz_min, xyz_max;
+} PyrDevelopParams;
+
+/* film: HOST grains of the whole image (height*width*bins); rgb_out: HOST, height*width*3 bytes, row-major RGB. Blocking. */
+int pyr_film_develop(const PyrFilmDesc* film, const PyrGrain* grains, const PyrDevelopParams* params, uint8_t* rgb_out, int device);
+/* Same with the film and the output resident on `device`; the PyrDevelopParams arrays stay HOST pointers (copied by the
+ * call); enqueued on `hip_stream`. */
+int pyr_film_develop_device(const PyrFilmDesc* film, const PyrGrain* grains_device, const PyrDevelopParams* params, uint8_t* rgb_device,
+                            int device, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

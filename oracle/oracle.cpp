@@ -2012,4 +2012,79 @@ float oracle_run_program(OracleScene* scene, uint32_t program, float wavelength,
     return v;
 }
 
+// ---- film development: main.rs:315-327 (final pass), spectrum_to_xyz :352-369, spectrum_to_tristimulus :371-418,
+// film::Spectrum::get film.rs:321-337, DevelopedPixels film.rs:282-313, Grain::develop film.rs:132-143.
+// [3P] palette 0.7.2: Xyz(D65) -> linear sRGB with the sRGB/D65 matrix, clamp to [0,1] (FromColor), sRGB transfer function,
+// u8 = round(255 * v). The crate derives its matrix from the primaries at run time and converts to u8 through a lookup
+// table; both may differ from the textbook constants used here in the last bit (unverifiable offline).
+int oracle_film_develop(const PyrFilmDesc* film, const PyrGrain* grains, const PyrDevelopParams* p, uint8_t* rgb_out) {
+    if (!film || !grains || !p || !rgb_out || !p->xyz_table) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    const uint32_t bins = film->bins;
+    const size_t pixels = (size_t)film->width * film->height;
+    const float min = film->wl_start, max = film->wl_start + film->wl_width;
+    auto xyz_get = [&](int channel, float w) { // Spectrum::Array::get on the interleaved table
+        const float* d = p->xyz_table;
+        const uint32_t n = p->xyz_count;
+        if (w <= p->xyz_min) return d[channel];
+        if (w >= p->xyz_max) return d[3 * (n - 1) + channel];
+        float normalized = (w - p->xyz_min) / (p->xyz_max - p->xyz_min);
+        float fi = normalized * ((float)n - 1.0f);
+        float fmin_ = std::trunc(fi);
+        uint32_t i0 = (uint32_t)fmin_;
+        float mix = fi - fmin_;
+        return d[3 * i0 + channel] * (1.0f - mix) + d[3 * (i0 + 1) + channel] * mix;
+    };
+    auto encode = [](float v) -> uint8_t { // sRGB transfer function, pow through f64
+        v = rmin(rmax(v, 0.0f), 1.0f);
+        float e = v <= 0.0031308f ? 12.92f * v : 1.055f * (float)std::pow((double)v, 1.0 / 2.4) - 0.055f;
+        e = rmin(rmax(e, 0.0f), 1.0f);
+        return (uint8_t)(e * 255.0f + 0.5f);
+    };
+    std::memset(rgb_out, 0, pixels * 3);
+    for (size_t px = 0; px < pixels; ++px) {
+        if ((px + 1) * bins >= pixels * bins) break; // DevelopedPixels::next stops when `end < len` fails: the last pixel is skipped
+        const PyrGrain* g = grains + px * bins;
+        auto sample = [&](float w, uint32_t i) {
+            float intensity;
+            if (w < min || w > max) {
+                intensity = 0.0f;
+            } else {
+                float normalized = (w - min) / (max - min);
+                float float_index = normalized * (float)bins;
+                uint32_t index = (uint32_t)std::min<float>(std::floor(float_index), (float)(bins - 1));
+                intensity = g[index].weight > 0.0f ? g[index].acc / g[index].weight : 0.0f;
+            }
+            if (p->filter) intensity = intensity * p->filter[i];
+            if (p->white_div) intensity = (intensity / p->white_div[i]) * p->white_mul[i];
+            return intensity;
+        };
+        float sum[3] = {0, 0, 0}, weight = 0.0f;
+        float wl_min = min;
+        uint32_t i = 0;
+        float spectrum_min = sample(wl_min, i);
+        float start[3] = {xyz_get(0, wl_min), xyz_get(1, wl_min), xyz_get(2, wl_min)};
+        while (wl_min < max) {
+            float wl_max = wl_min + p->step_size;
+            i += 1;
+            float spectrum_max = sample(wl_max, i < p->sample_count ? i : p->sample_count - 1);
+            float end[3] = {xyz_get(0, wl_max), xyz_get(1, wl_max), xyz_get(2, wl_max)};
+            float w = wl_max - wl_min;
+            for (int c = 0; c < 3; ++c) sum[c] += (start[c] * spectrum_min + end[c] * spectrum_max) * 0.5f * w;
+            weight += w;
+            wl_min = wl_max;
+            spectrum_min = spectrum_max;
+            for (int c = 0; c < 3; ++c) start[c] = end[c];
+        }
+        float xyz[3];
+        for (int c = 0; c < 3; ++c) xyz[c] = (weight == 0.0f ? sum[c] : sum[c] / weight) * p->xyz_scale;
+        float r = 3.2404542f * xyz[0] + -1.5371385f * xyz[1] + -0.4985314f * xyz[2];
+        float gg = -0.9692660f * xyz[0] + 1.8760108f * xyz[1] + 0.0415560f * xyz[2];
+        float b = 0.0556434f * xyz[0] + -0.2040259f * xyz[1] + 1.0572252f * xyz[2];
+        rgb_out[3 * px + 0] = encode(r);
+        rgb_out[3 * px + 1] = encode(gg);
+        rgb_out[3 * px + 2] = encode(b);
+    }
+    return PYR_OK;
+}
+
 } // extern "C"

@@ -95,6 +95,9 @@ uint32_t oracle_tile_order(uint32_t width, uint32_t height, uint32_t tile_size, 
 float oracle_run_program(OracleScene* scene, uint32_t program, float wavelength, const float normal[3],
                          const float incident[3], const float texture[2], int* wavelength_used);
 
+/* main.rs:315-327 + :352-418 + film.rs:282-337: develop a whole film into 8-bit sRGB ("next" row f1). */
+int oracle_film_develop(const PyrFilmDesc* film, const PyrGrain* grains, const PyrDevelopParams* params, uint8_t* rgb_out);
+
 #ifdef __cplusplus
 }
 #endif

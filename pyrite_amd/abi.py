@@ -205,6 +205,21 @@ class PyrBvhInfo(C.Structure):
     ]
 
 
+class PyrDevelopParams(C.Structure):
+    _fields_ = [
+        ("step_size", C.c_float),
+        ("xyz_scale", C.c_float),
+        ("sample_count", C.c_uint32),
+        ("filter", _fp),
+        ("white_div", _fp),
+        ("white_mul", _fp),
+        ("xyz_table", _fp),
+        ("xyz_count", C.c_uint32),
+        ("xyz_min", C.c_float),
+        ("xyz_max", C.c_float),
+    ]
+
+
 PyrProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint8, C.c_char_p)
 
 # Every entry point include/pyrite_gpu.h declares: name -> (restype, argtypes)
@@ -226,6 +241,8 @@ ENTRY_POINTS = {
     "pyr_scene_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(PyrCounters)]),
     "pyr_scene_intersect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pyr_scene_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(PyrBvhInfo)]),
+    "pyr_film_develop": (C.c_int, [C.POINTER(PyrFilmDesc), C.c_void_p, C.POINTER(PyrDevelopParams), C.c_void_p, C.c_int]),
+    "pyr_film_develop_device": (C.c_int, [C.POINTER(PyrFilmDesc), C.c_void_p, C.POINTER(PyrDevelopParams), C.c_void_p, C.c_int, C.c_void_p]),
 }
 
 

@@ -602,6 +602,67 @@ int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* 
     return PYR_OK;
 }
 
+static int develop_common(const PyrFilmDesc* film, const PyrGrain* grains_device, const PyrDevelopParams* p, uint8_t* rgb_device, hipStream_t stream,
+                          bool blocking) {
+    if (!(p->step_size > 0.0f) || p->sample_count == 0 || p->xyz_count < 2) return fail(PYR_ERR_INVALID_ARGUMENT, "bad development parameters");
+    if ((p->white_div == nullptr) != (p->white_mul == nullptr)) return fail(PYR_ERR_INVALID_ARGUMENT, "white_div and white_mul go together");
+    // the small per-wavelength tables are copied for the call (stream-ordered allocation, freed after the kernel)
+    const size_t n = p->sample_count;
+    float* tables = nullptr;
+    const size_t floats = 3 * n + 3 * (size_t)p->xyz_count;
+    HIP_TRY(hipMallocAsync((void**)&tables, floats * sizeof(float), stream));
+    std::vector<float> host(floats, 0.0f);
+    if (p->filter) std::memcpy(host.data(), p->filter, n * 4);
+    if (p->white_div) {
+        std::memcpy(host.data() + n, p->white_div, n * 4);
+        std::memcpy(host.data() + 2 * n, p->white_mul, n * 4);
+    }
+    std::memcpy(host.data() + 3 * n, p->xyz_table, 3 * (size_t)p->xyz_count * 4);
+    HIP_TRY(hipMemcpy(tables, host.data(), floats * sizeof(float), hipMemcpyHostToDevice)); // synchronous: `host` dies with this frame
+    DevelopLaunch D{};
+    D.film = *film;
+    D.grains = grains_device;
+    D.step_size = p->step_size;
+    D.xyz_scale = p->xyz_scale;
+    D.sample_count = p->sample_count;
+    D.filter = p->filter ? tables : nullptr;
+    D.white_div = p->white_div ? tables + n : nullptr;
+    D.white_mul = p->white_div ? tables + 2 * n : nullptr;
+    D.xyz_table = tables + 3 * n;
+    D.xyz_count = p->xyz_count;
+    D.xyz_min = p->xyz_min;
+    D.xyz_max = p->xyz_max;
+    D.rgb_out = rgb_device;
+    int rc = launch_develop(D, stream);
+    hipError_t e = hipFreeAsync(tables, stream);
+    if (rc != PYR_OK) return fail(rc, kernels_last_error());
+    if (e != hipSuccess) return hip_fail(e, "hipFreeAsync");
+    if (blocking) HIP_TRY(hipStreamSynchronize(stream));
+    return PYR_OK;
+}
+
+int pyr_film_develop_device(const PyrFilmDesc* film, const PyrGrain* grains_device, const PyrDevelopParams* params, uint8_t* rgb_device, int device,
+                            void* hip_stream) {
+    if (!film || !grains_device || !params || !rgb_device || !params->xyz_table) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    if (pyr_device_count() <= device || device < 0) return fail(PYR_ERR_DEVICE, "no such HIP device; pyrite_gpu has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    return develop_common(film, grains_device, params, rgb_device, (hipStream_t)hip_stream, false);
+}
+
+int pyr_film_develop(const PyrFilmDesc* film, const PyrGrain* grains, const PyrDevelopParams* params, uint8_t* rgb_out, int device) {
+    if (!film || !grains || !params || !rgb_out || !params->xyz_table) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    if (pyr_device_count() <= device || device < 0) return fail(PYR_ERR_DEVICE, "no such HIP device; pyrite_gpu has no CPU path");
+    HIP_TRY(hipSetDevice(device));
+    const size_t pixels = (size_t)film->width * film->height;
+    DeviceBuffer film_dev, rgb_dev;
+    int rc;
+    if ((rc = film_dev.upload(grains, pixels * film->bins * sizeof(PyrGrain))) != PYR_OK) return rc;
+    if ((rc = rgb_dev.alloc(pixels * 3)) != PYR_OK) return rc;
+    if ((rc = develop_common(film, (const PyrGrain*)film_dev.ptr, params, (uint8_t*)rgb_dev.ptr, nullptr, true)) != PYR_OK) return rc;
+    HIP_TRY(hipMemcpy(rgb_out, rgb_dev.ptr, pixels * 3, hipMemcpyDeviceToHost));
+    return PYR_OK;
+}
+
 int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out) {
     if (!scene || !out) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
     *out = scene->info;

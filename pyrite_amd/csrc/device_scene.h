@@ -107,6 +107,21 @@ struct IntersectLaunch {
     uint32_t reserve; // rays a wave reserves per atomic (set by launch_intersect)
 };
 
+struct DevelopLaunch {
+    PyrFilmDesc film;
+    const PyrGrain* grains; // device
+    float step_size, xyz_scale;
+    uint32_t sample_count;
+    const float* filter;    // device or nullptr
+    const float* white_div; // device or nullptr
+    const float* white_mul;
+    const float* xyz_table; // device
+    uint32_t xyz_count;
+    float xyz_min, xyz_max;
+    uint8_t* rgb_out; // device
+};
+int launch_develop(const DevelopLaunch& launch, void* stream);
+
 // launchers (kernels.hip)
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);

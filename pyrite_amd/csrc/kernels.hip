@@ -1709,6 +1709,93 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
     flush_counters<COUNT>(cnt, L.counters);
 }
 
+// ------------------------------------------------------------------------------------------------ film development
+// main.rs:315-327: every pixel spectrum -> spectrum_to_xyz (main.rs:352-418, trapezoid rule against the CIE observer
+// tables) -> linear sRGB -> sRGB u8. One thread per pixel; the film is read once (bins * 8 B per pixel), HBM-bound.
+// The last pixel is skipped as in DevelopedPixels::next (film.rs:299).
+__global__ __launch_bounds__(BLOCK) void develop_kernel(DevelopLaunch D) {
+    const size_t pixels = (size_t)D.film.width * D.film.height;
+    const uint32_t bins = D.film.bins;
+    const float min = D.film.wl_start, max = D.film.wl_start + D.film.wl_width;
+    for (size_t px = (size_t)blockIdx.x * BLOCK + threadIdx.x; px < pixels; px += (size_t)gridDim.x * BLOCK) {
+        uint8_t out[3] = {0, 0, 0};
+        if ((px + 1) * bins < pixels * bins) {
+            const PyrGrain* g = D.grains + px * bins;
+            auto xyz_get = [&](int channel, float w) {
+                const float* d = D.xyz_table;
+                const uint32_t n = D.xyz_count;
+                if (w <= D.xyz_min) return d[channel];
+                if (w >= D.xyz_max) return d[3 * (n - 1) + channel];
+                float normalized = (w - D.xyz_min) / (D.xyz_max - D.xyz_min);
+                float fi = normalized * ((float)n - 1.0f);
+                float fmin_ = truncf(fi);
+                uint32_t i0 = (uint32_t)fmin_;
+                float mix = fi - fmin_;
+                return d[3 * i0 + channel] * (1.0f - mix) + d[3 * (i0 + 1) + channel] * mix;
+            };
+            auto sample = [&](float w, uint32_t i) {
+                float intensity;
+                if (w < min || w > max) {
+                    intensity = 0.0f;
+                } else {
+                    float normalized = (w - min) / (max - min);
+                    float float_index = normalized * (float)bins;
+                    uint32_t index = (uint32_t)fminf(floorf(float_index), (float)(bins - 1));
+                    const PyrGrain gr = g[index];
+                    intensity = gr.weight > 0.0f ? gr.acc / gr.weight : 0.0f; // Grain::develop, film.rs:132-143
+                }
+                if (D.filter) intensity = intensity * D.filter[i];
+                if (D.white_div) intensity = (intensity / D.white_div[i]) * D.white_mul[i];
+                return intensity;
+            };
+            float sum[3] = {0, 0, 0}, weight = 0.0f;
+            float wl_min = min;
+            uint32_t i = 0;
+            float spectrum_min = sample(wl_min, i);
+            float start[3] = {xyz_get(0, wl_min), xyz_get(1, wl_min), xyz_get(2, wl_min)};
+            while (wl_min < max) {
+                float wl_max = wl_min + D.step_size;
+                i += 1;
+                float spectrum_max = sample(wl_max, i < D.sample_count ? i : D.sample_count - 1);
+                float end[3] = {xyz_get(0, wl_max), xyz_get(1, wl_max), xyz_get(2, wl_max)};
+                float w = wl_max - wl_min;
+                for (int c = 0; c < 3; ++c) sum[c] += (start[c] * spectrum_min + end[c] * spectrum_max) * 0.5f * w;
+                weight += w;
+                wl_min = wl_max;
+                spectrum_min = spectrum_max;
+                for (int c = 0; c < 3; ++c) start[c] = end[c];
+            }
+            float xyz[3];
+            for (int c = 0; c < 3; ++c) xyz[c] = (weight == 0.0f ? sum[c] : sum[c] / weight) * D.xyz_scale;
+            const float rgb[3] = {3.2404542f * xyz[0] + -1.5371385f * xyz[1] + -0.4985314f * xyz[2],
+                                  -0.9692660f * xyz[0] + 1.8760108f * xyz[1] + 0.0415560f * xyz[2],
+                                  0.0556434f * xyz[0] + -0.2040259f * xyz[1] + 1.0572252f * xyz[2]};
+            for (int c = 0; c < 3; ++c) {
+                float v = fminf(fmaxf(rgb[c], 0.0f), 1.0f);
+                float e = v <= 0.0031308f ? 12.92f * v : 1.055f * (float)pow((double)v, 1.0 / 2.4) - 0.055f;
+                e = fminf(fmaxf(e, 0.0f), 1.0f);
+                out[c] = (uint8_t)(e * 255.0f + 0.5f);
+            }
+        }
+        D.rgb_out[3 * px + 0] = out[0];
+        D.rgb_out[3 * px + 1] = out[1];
+        D.rgb_out[3 * px + 2] = out[2];
+    }
+}
+
+int launch_develop(const DevelopLaunch& launch, void* stream) {
+    const size_t pixels = (size_t)launch.film.width * launch.film.height;
+    if (pixels == 0) return PYR_OK;
+    uint32_t grid = (uint32_t)std::min<size_t>((pixels + BLOCK - 1) / BLOCK, 256 * 16);
+    hipLaunchKernelGGL(develop_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, launch);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("develop kernel launch: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    return PYR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 constexpr size_t kLdsSceneBytes = 8 * 1024; // nodes + primitives staged in LDS when they fit (C1, C2: < 3 KB)
 static bool scene_fits_lds(const DevScene& scene) { return (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48 <= kLdsSceneBytes; }

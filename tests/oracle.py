@@ -77,8 +77,22 @@ def lib():
         L.oracle_tile_order.restype = C.c_uint32
         L.oracle_run_program.argtypes = [C.c_void_p, C.c_uint32, C.c_float, F3, F3, C.c_float * 2, C.POINTER(C.c_int)]
         L.oracle_run_program.restype = C.c_float
+        L.oracle_film_develop.argtypes = [C.POINTER(abi.PyrFilmDesc), C.c_void_p, C.POINTER(abi.PyrDevelopParams), C.c_void_p]
         _lib = L
     return _lib
+
+
+def film_develop(film, step_size=2.0, filter=None, white=None):
+    """The oracle's restatement of main.rs:315-418 for a pyrite_amd Film -> uint8 [h, w, 3]."""
+    from pyrite_amd.develop import develop_params
+
+    p, keep = develop_params(film, step_size, filter, white)
+    desc = film.desc()
+    grains = np.ascontiguousarray(film.grains)
+    out = np.zeros((film.height, film.width, 3), dtype=np.uint8)
+    _check(lib().oracle_film_develop(C.byref(desc), grains.ctypes.data, C.byref(p), out.ctypes.data))
+    del keep
+    return out
 
 
 class OracleError(RuntimeError):
