@@ -34,8 +34,11 @@ int hip_fail(hipError_t e, const char* what) { return fail(PYR_ERR_DEVICE, std::
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
-    ~DeviceBuffer() {
+    ~DeviceBuffer() { release(); }
+    void release() {
         if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
     }
     int upload(const void* src, size_t n) {
         bytes = n;
@@ -180,9 +183,14 @@ struct PyrScene {
         spectrum_data, rgb_basis, counters;
     PyrCounters last_counters{};
     bool have_counters = false;
-    uint32_t* tail_count = nullptr; // device word: the ray-batch cursor of the intersect kernel
+    uint32_t* tail_count = nullptr; // device, kFeedBytes: the work-feed cursors of the intersect kernel
+    // wavefront scheduler: path pool (grown on demand, kept between renders) and the pinned word the round loop polls
+    DeviceBuffer wf_stage, wf_groups, wf_companions, wf_words;
+    uint32_t wf_slots = 0, wf_companion_rows = 0;
+    uint32_t* wf_host_flag = nullptr;
     ~PyrScene() {
         if (tail_count) (void)hipFree(tail_count);
+        if (wf_host_flag) (void)hipHostFree(wf_host_flag);
     }
 };
 
@@ -402,6 +410,42 @@ int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
 // Scheduler choice (kernels.hip): the bounce-synchronous walk wins when the scene lives in LDS and traversal is cheap
 // (C2: 573 vs 300 Msamples/s); the stage scheduler wins when traversal lengths are heavy tailed (C3: 110 vs 91).
 // PYRITE_SCHEDULER=sync|sm overrides; PYRITE_SM_LANES / PYRITE_SM_STEPS tune the stage scheduler.
+// Path pool of the wavefront scheduler: one slot per lane of `waves` virtual waves, at most PYRITE_WF_SLOTS (default 4 Mi)
+// slots = 1.3 GB at 10 spectrum samples. Kept on the scene between renders, regrown when a render needs more.
+int wavefront_pool(PyrScene* scene, const RenderLaunch& L, WfPool& pool) {
+    const char* e = std::getenv("PYRITE_WF_SLOTS");
+    uint64_t max_slots = e && *e ? std::strtoull(e, nullptr, 10) : (4ull << 20);
+    max_slots = std::max<uint64_t>(64, max_slots & ~63ull);
+    const uint64_t chunks = L.chunk_end - L.chunk_begin;
+    const uint32_t slots = (uint32_t)std::min<uint64_t>(chunks * 64ull, max_slots);
+    const uint32_t rows = 3 * (L.spectrum_samples - 1);
+    if (slots > scene->wf_slots || rows > scene->wf_companion_rows) {
+        scene->wf_stage.release();
+        scene->wf_groups.release();
+        scene->wf_companions.release();
+        const uint32_t cap = std::max(slots, scene->wf_slots), cap_rows = std::max(rows, scene->wf_companion_rows);
+        scene->wf_slots = scene->wf_companion_rows = 0;
+        int rc;
+        if ((rc = scene->wf_stage.alloc((size_t)cap * sizeof(uint32_t))) != PYR_OK) return rc;
+        if ((rc = scene->wf_groups.alloc((size_t)cap * kWfStateGroups * 16)) != PYR_OK) return rc;
+        if ((rc = scene->wf_companions.alloc((size_t)cap * std::max(cap_rows, 1u) * sizeof(float))) != PYR_OK) return rc;
+        scene->wf_slots = cap;
+        scene->wf_companion_rows = cap_rows;
+    }
+    if (!scene->wf_words.ptr) {
+        int rc = scene->wf_words.alloc(kFeedBytes + sizeof(uint32_t));
+        if (rc != PYR_OK) return rc;
+    }
+    if (!scene->wf_host_flag) HIP_TRY(hipHostMalloc((void**)&scene->wf_host_flag, sizeof(uint32_t)));
+    pool.n = slots;
+    pool.stage = (uint32_t*)scene->wf_stage.ptr;
+    pool.groups = (float*)scene->wf_groups.ptr;
+    pool.companions = (float*)scene->wf_companions.ptr;
+    pool.next = (uint32_t*)scene->wf_words.ptr;
+    pool.work_flag = (uint32_t*)scene->wf_words.ptr + kFeedSegments * kFeedCursorStride;
+    return PYR_OK;
+}
+
 int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stream) {
     if (L.chunk_end == L.chunk_begin) return PYR_OK;
     const char* e = std::getenv("PYRITE_SCHEDULER");
@@ -409,8 +453,18 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 1;
     else if (e && std::string(e) == "sync")
         L.scheduler = 0;
+    else if (e && std::string(e) == "wf")
+        L.scheduler = 2;
     else
         L.scheduler = scene_is_lds_resident(scene->dev) ? 0u : 1u;
+    if (L.scheduler == 2) {
+        WfPool pool{};
+        int rc = wavefront_pool(scene, L, pool);
+        if (rc != PYR_OK) return rc;
+        rc = launch_wavefront(scene->dev, L, count, stream, scene->num_cus, pool, scene->wf_host_flag);
+        if (rc != PYR_OK) return fail(rc, kernels_last_error());
+        return PYR_OK;
+    }
     const char* lanes = std::getenv("PYRITE_SM_LANES");
     const char* steps = std::getenv("PYRITE_SM_STEPS");
     L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
@@ -554,8 +608,8 @@ int pyr_scene_counters(PyrScene* scene, PyrCounters* out) {
 int pyr_scene_intersect_device(PyrScene* scene, const float* rays_device, uint32_t n, PyrHit* hits_device, void* hip_stream) {
     if (!scene || (n && (!rays_device || !hits_device))) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(scene->device));
-    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(scene->tail_count, 0, sizeof(uint32_t), (hipStream_t)hip_stream));
+    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, kFeedBytes));
+    HIP_TRY(hipMemsetAsync(scene->tail_count, 0, kFeedBytes, (hipStream_t)hip_stream));
     IntersectLaunch L{rays_device, hits_device, n, nullptr, scene->tail_count, (uint32_t)scene->num_cus};
     int rc = launch_intersect(scene->dev, L, false, hip_stream);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());
@@ -572,10 +626,10 @@ int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* 
     int rc;
     if ((rc = rays_dev.upload(rays, (size_t)n * 24)) != PYR_OK) return rc;
     if ((rc = hits_dev.alloc((size_t)n * sizeof(PyrHit))) != PYR_OK) return rc;
-    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, sizeof(uint32_t)));
+    if (!scene->tail_count) HIP_TRY(hipMalloc((void**)&scene->tail_count, kFeedBytes));
     IntersectLaunch L{(const float*)rays_dev.ptr, (PyrHit*)hits_dev.ptr, n, nullptr, scene->tail_count, (uint32_t)scene->num_cus};
     if (counters) {
-        HIP_TRY(hipMemset(scene->tail_count, 0, sizeof(uint32_t)));
+        HIP_TRY(hipMemset(scene->tail_count, 0, kFeedBytes));
         HIP_TRY(hipMemset(scene->counters.ptr, 0, sizeof(PyrCounters)));
         L.counters = (unsigned long long*)scene->counters.ptr;
         rc = launch_intersect(scene->dev, L, true, nullptr);
@@ -587,7 +641,7 @@ int pyr_scene_intersect(PyrScene* scene, const float* rays, uint32_t n, PyrHit* 
     hipEvent_t start, stop;
     HIP_TRY(hipEventCreate(&start));
     HIP_TRY(hipEventCreate(&stop));
-    HIP_TRY(hipMemset(scene->tail_count, 0, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(scene->tail_count, 0, kFeedBytes));
     HIP_TRY(hipEventRecord(start, nullptr));
     rc = launch_intersect(scene->dev, L, false, nullptr);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());

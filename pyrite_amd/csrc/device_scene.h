@@ -77,6 +77,8 @@ struct DevScene {
     uint32_t lds_table_floats; // > 0: the spectrum tables are staged into LDS (this many floats)
 };
 
+constexpr uint32_t kMaxStackDepth = 40; // >= kMaxBvhDepth (bvh.h): the deepest tree build_bvh produces
+
 // Everything one render launch needs besides the scene.
 struct RenderLaunch {
     PyrCamera camera;
@@ -93,18 +95,35 @@ struct RenderLaunch {
     float grains_per_wavelength; // bins / wl_width (film.rs:38)
     PyrGrain* film_out;
     unsigned long long* counters; // 9 words (PyrCounters order) or nullptr
-    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm)
+    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm), 2 = wavefront
     uint32_t sm_phase_lanes, sm_trav_steps; // stage scheduler: lanes that make a phase run; traversal steps per turn
+    uint32_t stack_lds; // traversal stack levels kept in LDS (set by launch_render; deeper levels spill to scratch in the sm kernel)
 };
+
+// Path pool of the wavefront scheduler (kernels.hip "Wavefront integrator"): n slots, all arrays [field][slot].
+struct WfPool {
+    uint32_t n;          // slots, a multiple of 64
+    uint32_t* stage;     // [n] stage word
+    float* groups;       // [kWfStateGroups][n] float4
+    float* companions;   // [3 * (spectrum_samples - 1)][n]
+    uint32_t* next;      // device: work-feed cursors of the traversal kernel (kFeedBytes)
+    uint32_t* work_flag; // device word: set by the logic kernel while any path still needs a ray
+};
+constexpr uint32_t kWfStateGroups = 12;
+
+// Work feed of the persistent traversal kernels: kFeedSegments cursor words, kFeedCursorStride words apart (kernels.hip WorkFeed).
+constexpr uint32_t kFeedSegments = 8, kFeedCursorStride = 64;
+constexpr size_t kFeedBytes = (size_t)kFeedSegments * kFeedCursorStride * sizeof(uint32_t);
 
 struct IntersectLaunch {
     const float* rays;
     PyrHit* hits;
     uint32_t n;
     unsigned long long* counters;
-    uint32_t* next;  // device word, zero at launch: the next ray of the batch to hand out
+    uint32_t* next;  // device, kFeedBytes, zero at launch: the work-feed cursors of the batch
     uint32_t num_cus;
     uint32_t reserve; // rays a wave reserves per atomic (set by launch_intersect)
+    uint32_t stack_lds; // traversal stack levels kept in LDS (set by launch_intersect)
 };
 
 struct DevelopLaunch {
@@ -125,6 +144,10 @@ int launch_develop(const DevelopLaunch& launch, void* stream);
 // launchers (kernels.hip)
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);
+// Wavefront render: alternates the logic and traversal kernels until every path of the launch has ended. Blocks on `stream`
+// (the loop's end is decided by the device). `host_flag` is one pinned host word.
+int launch_wavefront(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus, const WfPool& pool,
+                     volatile uint32_t* host_flag);
 const char* kernels_last_error();
 bool scene_is_lds_resident(const DevScene& scene);
 

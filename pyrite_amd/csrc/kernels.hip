@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "device_scene.h"
@@ -1255,6 +1256,29 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
 // on to shading while its neighbours keep walking the tree, and a lane whose path ends refills itself with the next
 // sample. Results are those of the synchronous walk bit for bit: per-path order of operations and RNG draws is unchanged.
 // =================================================================================================
+// Developer build only (-DPYR_PHASE_PROFILE, tools/phase_profile.py): per-phase wave cycles / active lanes / turns.
+#ifdef PYR_PHASE_PROFILE
+__device__ unsigned long long g_phase_prof[16];
+#define PROF_DECL unsigned long long prof_c[4] = {0, 0, 0, 0}, prof_l[4] = {0, 0, 0, 0}, prof_n[4] = {0, 0, 0, 0}
+#define PROF_BEGIN(ph, cond) const unsigned long long prof_t0_##ph = clock64(); prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
+#define PROF_END(ph) prof_c[ph] += clock64() - prof_t0_##ph
+#define PROF_LANES(ph, cond) prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
+#define PROF_FLUSH()                                                                                  \
+    if ((threadIdx.x & 63u) == 0)                                                                     \
+        for (int i = 0; i < 4; ++i) {                                                                 \
+            atomicAdd(&g_phase_prof[i], prof_c[i]);                                                   \
+            atomicAdd(&g_phase_prof[4 + i], prof_l[i]);                                               \
+            atomicAdd(&g_phase_prof[8 + i], prof_n[i]);                                               \
+        }
+#else
+#define PROF_DECL
+#define PROF_BEGIN(ph, cond)
+#define PROF_END(ph)
+#define PROF_LANES(ph, cond)
+#define PROF_FLUSH()
+#endif
+
+enum Touched : uint32_t { TOUCH_NEW = 1, TOUCH_BRIGHT = 2, TOUCH_REFL = 4, TOUCH_SHADE = 8, TOUCH_LIGHT = 16 };
 enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EXPOSE = 4, ST_DONE = 5 };
 
 struct Trav { // resumable World::intersect
@@ -1265,6 +1289,15 @@ struct Trav { // resumable World::intersect
     float u, v;
     bool shadow, blocked;
 };
+
+// Puts a query whose ray, limit and plane results are set at the root of the tree.
+DEV void trav_restart(Trav& t) {
+    t.inv = mk(1.0f / t.d.x, 1.0f / t.d.y, 1.0f / t.d.z);
+    t.limit_cull = t.limit * 1.001f + 1.0e-3f;
+    t.blocked = false;
+    t.node = 0;
+    t.sp = 0;
+}
 
 // Planes first (world.rs:277-285), then the tree from the root. Returns true when the query is already decided.
 template <bool COUNT>
@@ -1295,15 +1328,30 @@ DEV bool trav_begin(const DevScene& S, Trav& t, f3 o, f3 d, bool shadow, float l
             }
         }
     }
-    t.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    t.node = 0;
-    t.sp = 0;
+    trav_restart(t);
     return false;
 }
 
+// Traversal stack of the resumable walk: the first `lds_entries` levels live in LDS ([level][lane], conflict free), deeper
+// levels in the lane's scratch. A SAH tree over 819 k triangles is ~30 levels deep but a ray rarely holds more than a
+// dozen pending subtrees, so a short LDS part keeps the LDS footprint (and with it the waves per CU) independent of the
+// tree's worst-case depth while the deep end is touched by a few rays only.
+struct TravStack {
+    int* lds; // + threadIdx.x
+    int lds_entries;
+    int deep[kMaxStackDepth];
+    DEV void push(int sp, int value) {
+        if (sp < lds_entries)
+            lds[sp * BLOCK] = value;
+        else
+            deep[sp - lds_entries] = value;
+    }
+    DEV int pop(int sp) const { return sp < lds_entries ? lds[sp * BLOCK] : deep[sp - lds_entries]; }
+};
+
 // One node visit or one leaf. Returns true when the traversal has finished. Same tests, same order as traverse<>.
 template <bool COUNT>
-DEV bool trav_step(const SceneView& view, Trav& t, int* stack, Counters& cnt) {
+DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
     if (t.node >= 0) {
         const float4* nd = view.nodes + 4 * t.node;
         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
@@ -1322,7 +1370,7 @@ DEV bool trav_step(const SceneView& view, Trav& t, int* stack, Counters& cnt) {
         if (h0 && h1) {
             const bool swap = e1 < e0;
             t.node = swap ? c1 : c0;
-            stack[t.sp * BLOCK] = swap ? c0 : c1;
+            stack.push(t.sp, swap ? c0 : c1);
             t.sp++;
         } else if (h0) {
             t.node = c0;
@@ -1331,19 +1379,22 @@ DEV bool trav_step(const SceneView& view, Trav& t, int* stack, Counters& cnt) {
         } else {
             if (t.sp == 0) return true;
             t.sp--;
-            t.node = stack[t.sp * BLOCK];
+            t.node = stack.pop(t.sp);
         }
         return false;
     }
+    // A leaf is walked one primitive per step (the code in t.node shrinks: first + 1, count - 1), in leaf order. Looping over
+    // the whole leaf here made every wave pay for its fullest leaf (4 primitives) at each step while most lanes were at
+    // inner nodes: 17 % VALU lane occupancy in the traversal kernel (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU).
     const uint32_t code = (uint32_t)(-1 - t.node);
     const uint32_t first = code >> 3, count = code & 7u;
-    for (uint32_t k = 0; k < count; ++k) {
-        const float4 a = view.prims[3 * (first + k) + 0], b = view.prims[3 * (first + k) + 1];
+    if (count != 0) {
+        const float4 a = view.prims[3 * first + 0], b = view.prims[3 * first + 1];
         const uint32_t shape = __float_as_uint(a.w);
         float dist, u = 0.0f, v = 0.0f;
         bool ok;
         if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
-            const float4 c = view.prims[3 * (first + k) + 2];
+            const float4 c = view.prims[3 * first + 2];
             if (COUNT) cnt.triangle_tests++;
             ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t.o, t.d, dist, u, v);
         } else {
@@ -1364,33 +1415,23 @@ DEV bool trav_step(const SceneView& view, Trav& t, int* stack, Counters& cnt) {
                 t.v = v;
             }
         }
+        if (count > 1) {
+            t.node = -1 - (int)(((first + 1) << 3) | (count - 1));
+            return false;
+        }
     }
     if (t.sp == 0) return true;
     t.sp--;
-    t.node = stack[t.sp * BLOCK];
+    t.node = stack.pop(t.sp);
     return false;
 }
 
-template <bool COUNT, bool INTERP, bool LDS_SCENE>
-__global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, RenderLaunch L) {
-    extern __shared__ float lds[];
-    const uint32_t SS = L.spectrum_samples;
-    const uint32_t n_add = SS - 1;
-    Spectral spec{lds + threadIdx.x, SS};
-    int* stack = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
-    Counters cnt{};
-    const uint32_t lds_base_floats = (3 * SS + S0.stack_depth) * BLOCK;
-    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
-    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t waves_per_block = BLOCK / 64;
-    const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-    const uint32_t total_waves = gridDim.x * waves_per_block;
-    uint32_t chunk = L.chunk_begin + wave;
-
-    const int phase_lanes = (int)L.sm_phase_lanes, trav_steps = (int)L.sm_trav_steps;
+// Per-path state of the resumable integrator and the code of its phases; shared by the stage-scheduled kernel (state in
+// registers) and the wavefront kernels (state in HBM between phases).
+template <bool COUNT, bool INTERP>
+struct Walker {
     uint32_t stage = ST_NEW;
+    uint32_t chunk = 0; // next chunk of this lane's sample sequence (chunk_begin + wave, + total_waves, ...)
     Path p{};
     Trav t{};
     // context of the bounce in flight (between SHADE and the end of its next-event estimation)
@@ -1403,14 +1444,19 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
     uint32_t ls_material = 0, ls_color = 0;
     f3 ls_normal = mk(0, 0, 0);
     float ls_scale = 0.0f;
+    // what this visit changed, for schedulers that keep the state in memory between phases (dead code elsewhere)
+    uint32_t touched = 0;
 
     // tracer.rs:288-301 tail of a bounce + loop head :221: reflectance *= brdf, next ray, bounce count
-    auto finish_bounce = [&]() {
+    DEV void finish_bounce(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt) {
+        const uint32_t n_add = L.spectrum_samples - 1;
         if (b_has_brdf) {
             const float brdf = 2.0f * fabsf(dot(b_out, b_normal));
             p.refl *= brdf;
-            if (p.use_additional)
+            if (p.use_additional) {
                 for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+                touched |= TOUCH_REFL;
+            }
         }
         p.o = b_position;
         p.d = b_out;
@@ -1421,230 +1467,308 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
             if (COUNT) cnt.extension_rays++;
             stage = trav_begin<COUNT>(S, t, p.o, p.d, false, 0.0f, cnt) ? ST_SHADE : ST_TRAV;
         }
-    };
+    }
 
-    for (;;) {
-        const int nT = __popcll(__ballot(stage == ST_TRAV));
-        const int nS = __popcll(__ballot(stage == ST_SHADE));
-        const int nN = __popcll(__ballot(stage == ST_NEE));
-        const int nE = __popcll(__ballot(stage == ST_EXPOSE || stage == ST_NEW));
-        const int best = max(max(nT, nS), max(nN, nE));
-        if (best == 0) break; // every lane is DONE
-
-        // ---- EXPOSE / NEW: finish the path (simple.rs:133-139) and start the next sample (simple.rs:78-107)
-        if (nE >= phase_lanes || nE == best) {
-            if (stage == ST_EXPOSE) {
-                finish_path<COUNT>(L, p, spec, cnt);
-                stage = ST_NEW;
-            }
-            if (stage == ST_NEW) {
-                stage = ST_DONE;
-                while (chunk < L.chunk_end) {
-                    uint32_t tile;
-                    uint64_t iteration;
-                    TileArea area;
-                    const bool ok = locate_chunk(L, chunk, lane, tile, iteration, area);
-                    chunk += total_waves;
-                    if (ok) {
-                        start_sample(L, tile, iteration, area, p, spec);
-                        if (COUNT) cnt.samples++;
-                        if (L.bounces == 0) {
-                            stage = ST_EXPOSE;
-                        } else {
-                            if (COUNT) cnt.extension_rays++;
-                            stage = trav_begin<COUNT>(S, t, p.o, p.d, false, 0.0f, cnt) ? ST_SHADE : ST_TRAV;
-                        }
-                        break;
-                    }
-                }
-            }
+    // EXPOSE / NEW: finish the path (simple.rs:133-139) and start the next sample of this lane's sequence (simple.rs:78-107)
+    DEV void expose_and_restart(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt, uint32_t lane, uint32_t total_waves) {
+        if (stage == ST_EXPOSE) {
+            finish_path<COUNT>(L, p, spec, cnt);
+            stage = ST_NEW;
         }
-
-        // ---- SHADE: the hit/miss handling of tracer::trace (tracer.rs:222-341) up to the start of next-event estimation
-        if (nS >= phase_lanes || nS == best) {
-            if (stage == ST_SHADE) {
-                const f3 ray_o = t.o, ray_d = t.d;
-                if (t.shape == PYR_HIT_NONE) {
-                    uint32_t color = S.sky_program;
-                    if (p.sample_light) {
-                        for (uint32_t i = 0; i < S.num_lamps; ++i) {
-                            const DevLamp& l = S.lamps[i];
-                            if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
-                                color = l.color_program;
-                                break;
-                            }
-                        }
-                    }
-                    const Prepared q_prog = prepare_program<INTERP>(S, color);
-                    VmInput in{p.wl, -ray_d, ray_d};
-                    p.bright += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * p.refl;
-                    if (p.use_additional)
-                        for (uint32_t k = 0; k < n_add; ++k) {
-                            in.wavelength = spec.wl(k);
-                            spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * spec.refl(k);
-                        }
-                    stage = ST_EXPOSE;
-                } else {
-                    if (COUNT) cnt.shaded_hits++;
-                    Hit hit{t.closest, t.shape, t.u, t.v};
-                    f3 position, normal;
-                    uint32_t material_id;
-                    surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
-                    const PyrMaterial material = S.materials[material_id];
-                    const uint32_t pick = rng_choose(p.rng, material.num_components);
-                    const PyrComponent comp = S.components[material.first_component + pick];
-                    float component_probability = comp.selection_compensation;
-                    bool normal_dispersed = false;
-                    if (comp.probability_program >= 0) {
-                        VmInput pin{p.wl, normal, ray_d};
-                        component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
-                        normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
-                    }
-                    if (comp.bsdf == PYR_BSDF_EMISSIVE) {
-                        if (p.sample_light) {
-                            p.use_additional = !normal_dispersed && p.use_additional;
-                            const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
-                            VmInput in{p.wl, normal, ray_d};
-                            p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
-                            if (p.use_additional)
-                                for (uint32_t k = 0; k < n_add; ++k) {
-                                    in.wavelength = spec.wl(k);
-                                    spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * component_probability * spec.refl(k);
-                                }
-                        }
+        if (stage == ST_NEW) {
+            stage = ST_DONE;
+            while (chunk < L.chunk_end) {
+                uint32_t tile;
+                uint64_t iteration;
+                TileArea area;
+                const bool ok = locate_chunk(L, chunk, lane, tile, iteration, area);
+                chunk += total_waves;
+                if (ok) {
+                    start_sample(L, tile, iteration, area, p, spec);
+                    touched |= TOUCH_NEW | TOUCH_BRIGHT | TOUCH_REFL;
+                    if (COUNT) cnt.samples++;
+                    if (L.bounces == 0) {
                         stage = ST_EXPOSE;
                     } else {
-                        f3 out_direction;
-                        float scatter_probability = 1.0f;
-                        bool dispersed = false, has_brdf = false;
-                        if (comp.bsdf == PYR_BSDF_DIFFUSE) {
-                            f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                            out_direction = sample_hemisphere(p.rng, n);
-                            has_brdf = true;
-                        } else if (comp.bsdf == PYR_BSDF_MIRROR) {
-                            f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                            float perp = dot(ray_d, n) * 2.0f;
-                            out_direction = ray_d - n * perp;
-                        } else {
-                            dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
-                            float ior = comp.ior, env_ior = comp.env_ior;
-                            if (dispersed) {
-                                float wl = p.wl * 0.001f;
-                                ior = comp.ior + comp.dispersion / (wl * wl);
-                                env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
-                            }
-                            refract(ior, env_ior, ray_d, normal, p.rng, out_direction, scatter_probability);
-                        }
-                        const float bounce_probability = scatter_probability * component_probability;
-                        p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
-                        {
-                            const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
-                            VmInput in{p.wl, normal, ray_d};
-                            p.refl *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
-                            if (p.use_additional)
-                                for (uint32_t k = 0; k < n_add; ++k) {
-                                    in.wavelength = spec.wl(k);
-                                    spec.refl(k) *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
-                                }
-                        }
-                        b_position = position;
-                        b_normal = normal;
-                        b_out = out_direction;
-                        b_has_brdf = has_brdf;
-                        bool nee = false;
-                        if (p.events < 2) { // tracer.rs:257-280
-                            p.sample_light = !has_brdf || L.light_samples == 0;
-                            if (has_brdf) {
-                                p.events += 1;
-                                if (S.num_lamps > 0) {
-                                    nee_lamp = rng_range_usize(p.rng, S.num_lamps); // pick_lamp, world.rs:301-305
-                                    const float lamp_probability = 1.0f / (float)S.num_lamps;
-                                    b_nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                                    nee_probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
-                                    nee_i = 0;
-                                    ls_pending = false;
-                                    nee = true;
-                                }
-                            }
-                        } else {
-                            p.sample_light = true;
-                        }
-                        if (nee)
-                            stage = ST_NEE;
-                        else
-                            finish_bounce();
+                        if (COUNT) cnt.extension_rays++;
+                        stage = trav_begin<COUNT>(S, t, p.o, p.d, false, 0.0f, cnt) ? ST_SHADE : ST_TRAV;
                     }
-                }
-            }
-        }
-
-        // ---- NEE: trace_direct (tracer.rs:347-442), one light sample per visit: account for the shadow ray that came back,
-        //      then draw the next sample that needs one
-        if (nN >= phase_lanes || nN == best) {
-            if (stage == ST_NEE) {
-                if (ls_pending) {
-                    ls_pending = false;
-                    if (!t.blocked) {
-                        uint32_t l_color = ls_color;
-                        float material_probability = 1.0f;
-                        bool l_dispersed = false;
-                        f3 target_normal = -t.d;
-                        if (ls_physical) {
-                            const PyrMaterial lm = S.materials[ls_material];
-                            const uint32_t e_pick = rng_choose(p.rng, lm.num_emissive);
-                            const PyrComponent ec = S.components[lm.first_emissive + e_pick];
-                            material_probability = ec.selection_compensation;
-                            if (ec.probability_program >= 0) {
-                                VmInput pin{p.wl, ls_normal, t.d};
-                                material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
-                                l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
-                            }
-                            l_color = ec.color_program;
-                            target_normal = ls_normal;
-                        }
-                        const float l_probability = ls_scale * material_probability;
-                        const Prepared q_prog = prepare_program<INTERP>(S, l_color);
-                        VmInput in{p.wl, target_normal, t.d};
-                        p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
-                        if (p.use_additional && !l_dispersed)
-                            for (uint32_t k = 0; k < n_add; ++k) {
-                                in.wavelength = spec.wl(k);
-                                spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
-                            }
-                    }
-                }
-                const DevLamp& lamp = S.lamps[nee_lamp];
-                while (nee_i < L.light_samples) {
-                    const LampSample ls = lamp_sample(lamp, p.rng, b_position);
-                    nee_i++;
-                    const float cos_out = fmaxf(dot(b_nff, ls.direction), 0.0f);
-                    if (!(cos_out > 0.0f)) continue;
-                    if (COUNT) cnt.shadow_rays++;
-                    const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
-                    ls_scale = ls.weight * nee_probability * (2.0f * fabsf(dot(ls.direction, b_nff)));
-                    ls_physical = ls.physical;
-                    ls_material = ls.material;
-                    ls_color = ls.color;
-                    ls_normal = ls.normal;
-                    ls_pending = true;
-                    // a shadow ray decided by a plane alone comes straight back to this phase
-                    stage = trav_begin<COUNT>(S, t, b_position, ls.direction, true, limit, cnt) ? ST_NEE : ST_TRAV;
                     break;
-                }
-                if (stage == ST_NEE && !ls_pending) finish_bounce();
-            }
-        }
-
-        // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
-        if (nT >= phase_lanes || nT == best) {
-            for (int step = 0; step < trav_steps; ++step) {
-                if (stage == ST_TRAV) {
-                    if (trav_step<COUNT>(view, t, stack, cnt)) stage = t.shadow ? ST_NEE : ST_SHADE;
                 }
             }
         }
     }
+
+    // SHADE: the hit/miss handling of tracer::trace (tracer.rs:222-341) up to the start of next-event estimation
+    DEV void shade(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt) {
+        if (stage != ST_SHADE) return;
+        touched |= TOUCH_SHADE | TOUCH_BRIGHT | TOUCH_REFL;
+        const uint32_t n_add = L.spectrum_samples - 1;
+        const f3 ray_o = t.o, ray_d = t.d;
+        if (t.shape == PYR_HIT_NONE) {
+            uint32_t color = S.sky_program;
+            if (p.sample_light) {
+                for (uint32_t i = 0; i < S.num_lamps; ++i) {
+                    const DevLamp& l = S.lamps[i];
+                    if (l.kind == PYR_LAMP_DIRECTIONAL && dot(ld3(l.v), ray_d) >= l.width) {
+                        color = l.color_program;
+                        break;
+                    }
+                }
+            }
+            const Prepared q_prog = prepare_program<INTERP>(S, color);
+            VmInput in{p.wl, -ray_d, ray_d};
+            p.bright += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * p.refl;
+            if (p.use_additional)
+                for (uint32_t k = 0; k < n_add; ++k) {
+                    in.wavelength = spec.wl(k);
+                    spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * spec.refl(k);
+                }
+            stage = ST_EXPOSE;
+            return;
+        }
+        if (COUNT) cnt.shaded_hits++;
+        Hit hit{t.closest, t.shape, t.u, t.v};
+        f3 position, normal;
+        uint32_t material_id;
+        surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
+        const PyrMaterial material = S.materials[material_id];
+        const uint32_t pick = rng_choose(p.rng, material.num_components);
+        const PyrComponent comp = S.components[material.first_component + pick];
+        float component_probability = comp.selection_compensation;
+        bool normal_dispersed = false;
+        if (comp.probability_program >= 0) {
+            VmInput pin{p.wl, normal, ray_d};
+            component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+            normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
+        }
+        if (comp.bsdf == PYR_BSDF_EMISSIVE) {
+            if (p.sample_light) {
+                p.use_additional = !normal_dispersed && p.use_additional;
+                const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
+                VmInput in{p.wl, normal, ray_d};
+                p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
+                if (p.use_additional)
+                    for (uint32_t k = 0; k < n_add; ++k) {
+                        in.wavelength = spec.wl(k);
+                        spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * component_probability * spec.refl(k);
+                    }
+            }
+            stage = ST_EXPOSE;
+            return;
+        }
+        f3 out_direction;
+        float scatter_probability = 1.0f;
+        bool dispersed = false, has_brdf = false;
+        if (comp.bsdf == PYR_BSDF_DIFFUSE) {
+            f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+            out_direction = sample_hemisphere(p.rng, n);
+            has_brdf = true;
+        } else if (comp.bsdf == PYR_BSDF_MIRROR) {
+            f3 n = dot(ray_d, normal) < 0.0f ? normal : -normal;
+            float perp = dot(ray_d, n) * 2.0f;
+            out_direction = ray_d - n * perp;
+        } else {
+            dispersed = comp.dispersion != 0.0f || comp.env_dispersion != 0.0f;
+            float ior = comp.ior, env_ior = comp.env_ior;
+            if (dispersed) {
+                float wl = p.wl * 0.001f;
+                ior = comp.ior + comp.dispersion / (wl * wl);
+                env_ior = comp.env_ior + comp.env_dispersion / (wl * wl);
+            }
+            refract(ior, env_ior, ray_d, normal, p.rng, out_direction, scatter_probability);
+        }
+        const float bounce_probability = scatter_probability * component_probability;
+        p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
+        {
+            const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
+            VmInput in{p.wl, normal, ray_d};
+            p.refl *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
+            if (p.use_additional)
+                for (uint32_t k = 0; k < n_add; ++k) {
+                    in.wavelength = spec.wl(k);
+                    spec.refl(k) *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
+                }
+        }
+        b_position = position;
+        b_normal = normal;
+        b_out = out_direction;
+        b_has_brdf = has_brdf;
+        bool nee = false;
+        if (p.events < 2) { // tracer.rs:257-280
+            p.sample_light = !has_brdf || L.light_samples == 0;
+            if (has_brdf) {
+                p.events += 1;
+                if (S.num_lamps > 0) {
+                    nee_lamp = rng_range_usize(p.rng, S.num_lamps); // pick_lamp, world.rs:301-305
+                    const float lamp_probability = 1.0f / (float)S.num_lamps;
+                    b_nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
+                    nee_probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                    nee_i = 0;
+                    ls_pending = false;
+                    nee = true;
+                }
+            }
+        } else {
+            p.sample_light = true;
+        }
+        if (nee)
+            stage = ST_NEE;
+        else
+            finish_bounce(S, L, spec, cnt);
+    }
+
+    // NEE: trace_direct (tracer.rs:347-442), one light sample per visit: account for the shadow ray that came back, then
+    // draw the next sample that needs one
+    DEV void next_event(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt) {
+        if (stage != ST_NEE) return;
+        const uint32_t n_add = L.spectrum_samples - 1;
+        if (ls_pending) {
+            ls_pending = false;
+            if (!t.blocked) {
+                uint32_t l_color = ls_color;
+                float material_probability = 1.0f;
+                bool l_dispersed = false;
+                f3 target_normal = -t.d;
+                if (ls_physical) {
+                    const PyrMaterial lm = S.materials[ls_material];
+                    const uint32_t e_pick = rng_choose(p.rng, lm.num_emissive);
+                    const PyrComponent ec = S.components[lm.first_emissive + e_pick];
+                    material_probability = ec.selection_compensation;
+                    if (ec.probability_program >= 0) {
+                        VmInput pin{p.wl, ls_normal, t.d};
+                        material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                        l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
+                    }
+                    l_color = ec.color_program;
+                    target_normal = ls_normal;
+                }
+                const float l_probability = ls_scale * material_probability;
+                touched |= TOUCH_BRIGHT;
+                const Prepared q_prog = prepare_program<INTERP>(S, l_color);
+                VmInput in{p.wl, target_normal, t.d};
+                p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
+                if (p.use_additional && !l_dispersed)
+                    for (uint32_t k = 0; k < n_add; ++k) {
+                        in.wavelength = spec.wl(k);
+                        spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
+                    }
+            }
+        }
+        const DevLamp& lamp = S.lamps[nee_lamp];
+        while (nee_i < L.light_samples) {
+            const LampSample ls = lamp_sample(lamp, p.rng, b_position);
+            nee_i++;
+            const float cos_out = fmaxf(dot(b_nff, ls.direction), 0.0f);
+            if (!(cos_out > 0.0f)) continue;
+            if (COUNT) cnt.shadow_rays++;
+            const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
+            ls_scale = ls.weight * nee_probability * (2.0f * fabsf(dot(ls.direction, b_nff)));
+            ls_physical = ls.physical;
+            ls_material = ls.material;
+            ls_color = ls.color;
+            ls_normal = ls.normal;
+            ls_pending = true;
+            touched |= TOUCH_LIGHT;
+            // a shadow ray decided by a plane alone comes straight back to this phase
+            stage = trav_begin<COUNT>(S, t, b_position, ls.direction, true, limit, cnt) ? ST_NEE : ST_TRAV;
+            break;
+        }
+        if (stage == ST_NEE && !ls_pending) finish_bounce(S, L, spec, cnt);
+    }
+};
+
+template <bool COUNT, bool INTERP, bool LDS_SCENE>
+__global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, RenderLaunch L) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    Spectral spec{lds + threadIdx.x, SS};
+    TravStack stack;
+    stack.lds = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
+    stack.lds_entries = (int)L.stack_lds;
+    Counters cnt{};
+    const uint32_t lds_base_floats = (3 * SS + L.stack_lds) * BLOCK;
+    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
+    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t waves_per_block = BLOCK / 64;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const int phase_lanes = (int)L.sm_phase_lanes, trav_steps = (int)L.sm_trav_steps;
+    Walker<COUNT, INTERP> w;
+    w.chunk = L.chunk_begin + blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+
+    PROF_DECL;
+    for (;;) {
+        const int nT = __popcll(__ballot(w.stage == ST_TRAV));
+        const int nS = __popcll(__ballot(w.stage == ST_SHADE));
+        const int nN = __popcll(__ballot(w.stage == ST_NEE));
+        const int nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+        const int best = max(max(nT, nS), max(nN, nE));
+        if (best == 0) break; // every lane is DONE
+
+        if (nE >= phase_lanes || nE == best) {
+            PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
+            w.expose_and_restart(S, L, spec, cnt, lane, total_waves);
+            PROF_END(0);
+        }
+        if (nS >= phase_lanes || nS == best) {
+            PROF_BEGIN(1, w.stage == ST_SHADE);
+            w.shade(S, L, spec, cnt);
+            PROF_END(1);
+        }
+        if (nN >= phase_lanes || nN == best) {
+            PROF_BEGIN(2, w.stage == ST_NEE);
+            w.next_event(S, L, spec, cnt);
+            PROF_END(2);
+        }
+        // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
+        if (nT >= phase_lanes || nT == best) {
+#ifdef PYR_PHASE_PROFILE
+            const unsigned long long prof_t0_3 = clock64();
+#endif
+            for (int step = 0; step < trav_steps; ++step) {
+                PROF_LANES(3, w.stage == ST_TRAV);
+                if (w.stage == ST_TRAV) {
+                    if (trav_step<COUNT>(view, w.t, stack, cnt)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+                }
+            }
+            PROF_END(3);
+        }
+    }
+    PROF_FLUSH();
     flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ------------------------------------------------------------------------------------------------ work feed
+// Hands the items [0, n) of a batch to persistent waves. One cursor word serves only ~88 M atomics/s (they serialise in
+// one L2 channel), which capped a 4 M-item batch at 0.47 ms even with 128-item reservations, so the batch is cut into
+// kFeedSegments contiguous segments with a cursor each (on its own cache line); a workgroup starts in segment
+// blockIdx % 8 -- workgroups are dealt round-robin to the 8 XCDs, so an XCD mostly walks its own segment through its own
+// L2 -- and moves on to the next segment when it finds one drained. All fields are wave-uniform.
+struct WorkFeed {
+    uint32_t next = 0, end = 0; // this wave's reserved slice
+    uint32_t segment = 0, visited = 0;
+    bool drained = false;
+};
+DEV uint32_t feed_segment_begin(uint32_t n, uint32_t segment) { return (uint32_t)(((uint64_t)n * segment / kFeedSegments) & ~63ull); }
+DEV uint32_t feed_segment_end(uint32_t n, uint32_t segment) { return segment + 1 == kFeedSegments ? n : feed_segment_begin(n, segment + 1); }
+// Makes sure the wave holds a non-empty slice, or marks the feed drained.
+DEV void feed_reserve(WorkFeed& f, uint32_t* cursors, uint32_t n, uint32_t reserve, uint32_t lane) {
+    while (f.next == f.end && !f.drained) {
+        const uint32_t begin = feed_segment_begin(n, f.segment), end = feed_segment_end(n, f.segment);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&cursors[f.segment * kFeedCursorStride], reserve);
+        base = __shfl(base, 0, 64);
+        if (base < end - begin) {
+            f.next = begin + base;
+            f.end = begin + min(base + reserve, end - begin);
+        } else if (++f.visited == kFeedSegments) {
+            f.drained = true;
+        } else {
+            f.segment = (f.segment + 1) % kFeedSegments;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ intersect kernel
@@ -1655,43 +1779,37 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectLaunch L) {
     extern __shared__ int lds_stack[];
-    int* stack = lds_stack + threadIdx.x;
+    TravStack stack;
+    stack.lds = lds_stack + threadIdx.x;
+    stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
     const SceneView view{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
-    const uint32_t kReserve = L.reserve; // rays a wave takes from the batch per atomic (one word serves only ~88 M atomics/s)
     bool busy = false;
     uint32_t ray = 0;
     Trav t{};
-    uint32_t res_next = 0, res_end = 0; // this wave's reserved slice of the batch (wave-uniform)
-    bool drained = false;               // the batch has been handed out completely and the reserve is empty
+    WorkFeed feed;
+    feed.segment = blockIdx.x % kFeedSegments;
     for (;;) {
         const unsigned long long idle_mask = __ballot(!busy);
         const int idle = __popcll(idle_mask);
-        if (!drained && (idle >= kRefillLanes || idle == 64)) {
-            if (res_next == res_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(L.next, kReserve);
-                base = __shfl(base, 0, 64);
-                res_next = min(base, L.n);
-                res_end = min(base + kReserve, L.n);
-                if (res_next == res_end) drained = true;
-            }
-            if (!drained) {
-                const uint32_t available = res_end - res_next;
+        if (!feed.drained && (idle >= kRefillLanes || idle == 64)) {
+            feed_reserve(feed, L.next, L.n, L.reserve, lane);
+            if (!feed.drained) {
+                const uint32_t available = feed.end - feed.next;
                 const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (!busy && rank < available) {
-                    ray = res_next + rank;
+                    ray = feed.next + rank;
                     const float* r = L.rays + 6 * (size_t)ray;
                     trav_begin<COUNT>(S, t, ld3(r), ld3(r + 3), false, 0.0f, cnt);
                     busy = true;
                 }
-                res_next += min((uint32_t)idle, available);
+                feed.next += min((uint32_t)idle, available);
             }
         }
         if (__ballot(busy) == 0) {
-            if (drained) break;
+            if (feed.drained) break;
             continue;
         }
         for (int step = 0; step < kSteps; ++step) {
@@ -1707,6 +1825,237 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
         }
     }
     flush_counters<COUNT>(cnt, L.counters);
+}
+
+// =================================================================================================
+// Wavefront integrator (wf_logic_kernel + wf_trav_kernel) -- big scenes
+//
+// On a scene that lives in HBM the stage-scheduled kernel is latency bound: its 128 registers and ~40 KB of LDS per
+// workgroup allow 4 waves per SIMD, and measured speed follows that occupancy (2 -> 3 -> 4 workgroups per CU: 103 -> 135
+// -> 160 Msamples/s on C3) while 71 % of its wave cycles are tree walking at half lane occupancy. The wavefront form
+// splits the state machine at the ray: path state lives in a pool in HBM (288 GB: 4 M paths are 1.3 GB),
+//     wf_logic_kernel   one thread per pool slot: runs SHADE / NEE / EXPOSE / NEW (the Walker phases above) until the
+//                       path needs a ray, stores the state and the ray
+//     wf_trav_kernel    persistent waves with dynamic fetch over the pool (the intersect kernel's loop: 63 registers,
+//                       8 waves per SIMD, short LDS stack), writes the hit back
+// and the host alternates the two until no path has a ray left. Slot s owns the sample sequence of "wave" s / 64, lane
+// s % 64 of the chunk schedule, exactly as a lane of the stage-scheduled kernel does, and runs the same Walker code in the
+// same order, so films are identical to the other schedulers'.
+// =================================================================================================
+constexpr uint32_t WF_STAGE_MASK = 0xffu, WF_BLOCKED = 0x100u, WF_SHADOW = 0x200u;
+
+DEV float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+DEV f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+// State groups (float4 each, [group][slot]):
+//   0 chunk | bounce, events, flags | nee_lamp | nee_i        6 closest, shape, u, v (planes' result in, hit out)
+//   1 rng                                                     7 b_position     8 b_normal     9 b_out     10 b_nff
+//   2 px, py, wl, bright                                      11 ls_normal
+//   3 refl, nee_probability, ls_scale, ls_color
+//   4 ray origin, limit        5 ray direction, ls_material
+// A visit loads what its entry stage reads (a path coming back from an extension ray does not need the light-sample
+// context, one coming back from a shadow ray does not need the hit) and stores what it changed (Walker::touched).
+template <bool COUNT, bool INTERP>
+DEV void wf_load(const WfPool& P, uint32_t slot, uint32_t word, bool planes, Walker<COUNT, INTERP>& w, Spectral& spec, uint32_t n_comp) {
+    w.stage = word & WF_STAGE_MASK;
+    w.t.blocked = (word & WF_BLOCKED) != 0;
+    w.t.shadow = (word & WF_SHADOW) != 0;
+    const float4* g = reinterpret_cast<const float4*>(P.groups) + slot;
+    const size_t n = P.n;
+    const float4 g0 = g[0 * n];
+    w.chunk = __float_as_uint(g0.x);
+    if (w.stage == ST_NEW) return;
+    const float4 g1 = g[1 * n], g2 = g[2 * n], g3 = g[3 * n], g5 = g[5 * n];
+    const uint32_t packed = __float_as_uint(g0.y);
+    w.p.bounce = packed & 0xffffu;
+    w.p.events = (packed >> 16) & 0xffu;
+    w.p.use_additional = (packed >> 24) & 1u;
+    w.p.sample_light = (packed >> 25) & 1u;
+    w.b_has_brdf = (packed >> 26) & 1u;
+    w.ls_pending = (packed >> 27) & 1u;
+    w.ls_physical = (packed >> 28) & 1u;
+    w.nee_lamp = __float_as_uint(g0.z);
+    w.nee_i = __float_as_uint(g0.w);
+    w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
+    w.p.px = g2.x, w.p.py = g2.y, w.p.wl = g2.z, w.p.bright = g2.w;
+    w.p.refl = g3.x, w.nee_probability = g3.y, w.ls_scale = g3.z, w.ls_color = __float_as_uint(g3.w);
+    w.t.d = xyz(g5), w.ls_material = __float_as_uint(g5.w);
+    if (w.stage == ST_NEE) {
+        const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n], g10 = g[10 * n], g11 = g[11 * n];
+        w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9), w.b_nff = xyz(g10), w.ls_normal = xyz(g11);
+        w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event)
+    } else {
+        const float4 g4 = g[4 * n];
+        w.t.o = xyz(g4), w.t.limit = g4.w;
+        if (planes || w.stage == ST_SHADE) {
+            const float4 g6 = g[6 * n];
+            w.t.closest = g6.x, w.t.shape = __float_as_uint(g6.y), w.t.u = g6.z, w.t.v = g6.w;
+        }
+    }
+    w.p.o = w.t.o, w.p.d = w.t.d;
+    const float* c = P.companions + slot;
+    for (uint32_t k = 0; k < n_comp; ++k) {
+        spec.wl(k) = c[(size_t)(0 * n_comp + k) * n];
+        spec.bright(k) = c[(size_t)(1 * n_comp + k) * n];
+        spec.refl(k) = c[(size_t)(2 * n_comp + k) * n];
+    }
+}
+
+template <bool COUNT, bool INTERP>
+DEV void wf_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUNT, INTERP>& w, Spectral& spec, uint32_t n_comp) {
+    float4* g = reinterpret_cast<float4*>(P.groups) + slot;
+    const size_t n = P.n;
+    const uint32_t packed = (w.p.bounce & 0xffffu) | ((w.p.events & 0xffu) << 16) | ((uint32_t)w.p.use_additional << 24) |
+                            ((uint32_t)w.p.sample_light << 25) | ((uint32_t)w.b_has_brdf << 26) | ((uint32_t)w.ls_pending << 27) |
+                            ((uint32_t)w.ls_physical << 28);
+    g[0 * n] = make_float4(__uint_as_float(w.chunk), __uint_as_float(packed), __uint_as_float(w.nee_lamp), __uint_as_float(w.nee_i));
+    P.stage[slot] = w.stage | (w.t.shadow ? WF_SHADOW : 0u);
+    if (w.stage == ST_DONE) return;
+    g[1 * n] = make_float4(__uint_as_float(w.p.rng.x), __uint_as_float(w.p.rng.y), __uint_as_float(w.p.rng.z), __uint_as_float(w.p.rng.w));
+    g[2 * n] = make_float4(w.p.px, w.p.py, w.p.wl, w.p.bright);
+    g[3 * n] = make_float4(w.p.refl, w.nee_probability, w.ls_scale, __uint_as_float(w.ls_color));
+    g[4 * n] = mk4(w.t.o, w.t.limit);
+    g[5 * n] = mk4(w.t.d, __uint_as_float(w.ls_material));
+    if (planes) g[6 * n] = make_float4(w.t.closest, __uint_as_float(w.t.shape), w.t.u, w.t.v);
+    if (w.touched & TOUCH_SHADE) {
+        g[7 * n] = mk4(w.b_position, 0.0f);
+        g[8 * n] = mk4(w.b_normal, 0.0f);
+        g[9 * n] = mk4(w.b_out, 0.0f);
+        g[10 * n] = mk4(w.b_nff, 0.0f);
+    }
+    if (w.touched & TOUCH_LIGHT) g[11 * n] = mk4(w.ls_normal, 0.0f);
+    float* c = P.companions + slot;
+    if (w.touched & TOUCH_NEW)
+        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(0 * n_comp + k) * n] = spec.wl(k);
+    if (w.touched & TOUCH_BRIGHT)
+        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(1 * n_comp + k) * n] = spec.bright(k);
+    if (w.touched & TOUCH_REFL)
+        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(2 * n_comp + k) * n] = spec.refl(k);
+}
+
+__global__ __launch_bounds__(BLOCK) void wf_init_kernel(WfPool P, uint32_t chunk_begin) {
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= P.n) return;
+    P.stage[slot] = ST_NEW;
+    reinterpret_cast<float4*>(P.groups)[slot] = make_float4(__uint_as_float(chunk_begin + slot / 64u), 0.0f, 0.0f, 0.0f);
+}
+
+template <bool COUNT, bool INTERP>
+__global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderLaunch L, WfPool P) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    Spectral spec{lds + threadIdx.x, SS};
+    Counters cnt{};
+    const DevScene S = stage_tables(S0, lds, 3 * SS * BLOCK);
+    if (blockIdx.x == 0 && threadIdx.x < kFeedSegments) P.next[threadIdx.x * kFeedCursorStride] = 0; // the traversal kernel that follows starts afresh
+    // The workgroup owns BLOCK consecutive slots. Its threads take them sorted by entry stage (SHADE, NEE, NEW, done) so that
+    // a wave runs one phase body instead of every body at partial occupancy; the slots stay within one 4 KB window per state
+    // group, so the permuted loads and stores touch the same cache lines as unpermuted ones.
+    __shared__ uint32_t wave_counts[BLOCK / 64][4];
+    __shared__ uint16_t sorted_slot[BLOCK];
+    const uint32_t first_slot = blockIdx.x * BLOCK;
+    uint32_t my_word = ST_DONE;
+    if (first_slot + threadIdx.x < P.n) my_word = P.stage[first_slot + threadIdx.x];
+    const uint32_t my_stage = my_word & WF_STAGE_MASK;
+    const uint32_t key = my_stage == ST_SHADE ? 0u : (my_stage == ST_NEE ? 1u : (my_stage == ST_DONE ? 3u : 2u));
+    const uint32_t lane_id = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
+    uint32_t rank_in_wave = 0;
+    for (uint32_t k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(key == k);
+        if (key == k) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane_id) - 1ull));
+        if (lane_id == 0) wave_counts[wave_id][k] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t position = rank_in_wave;
+    for (uint32_t k = 0; k < 4; ++k)
+        for (uint32_t v = 0; v < BLOCK / 64; ++v)
+            if (k < key || (k == key && v < wave_id)) position += wave_counts[v][k];
+    sorted_slot[position] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    const uint32_t slot = first_slot + sorted_slot[threadIdx.x];
+    const bool live = slot < P.n;
+    const uint32_t n_comp = SS - 1;
+    const uint32_t total_waves = P.n / 64u;
+    Walker<COUNT, INTERP> w;
+    w.stage = ST_DONE;
+    const bool planes = S.num_planes != 0;
+    if (live) {
+        const uint32_t word = P.stage[slot];
+        if ((word & WF_STAGE_MASK) != ST_DONE) wf_load(P, slot, word, planes, w, spec, n_comp);
+    }
+    const bool had_work = w.stage != ST_DONE;
+    for (;;) {
+        const bool any_shade = __ballot(w.stage == ST_SHADE) != 0;
+        const bool any_nee = __ballot(w.stage == ST_NEE) != 0;
+        const bool any_end = __ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0;
+        if (!(any_shade || any_nee || any_end)) break; // every lane holds a ray to trace, or is done
+        if (any_shade) w.shade(S, L, spec, cnt);
+        if (__ballot(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
+        if (__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
+    }
+    if (had_work) wf_store(P, slot, planes, w, spec, n_comp);
+    if (__ballot(w.stage == ST_TRAV) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u;
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, uint32_t reserve, uint32_t stack_lds, unsigned long long* counters) {
+    extern __shared__ int lds_stack[];
+    TravStack stack;
+    stack.lds = lds_stack + threadIdx.x;
+    stack.lds_entries = (int)stack_lds;
+    Counters cnt{};
+    const SceneView view{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr int kRefillLanes = 16, kSteps = 4;
+    const size_t n = P.n;
+    bool busy = false;
+    uint32_t slot = 0;
+    Trav t{};
+    WorkFeed feed;
+    feed.segment = blockIdx.x % kFeedSegments;
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!busy);
+        const int idle = __popcll(idle_mask);
+        if (!feed.drained && (idle >= kRefillLanes || idle == 64)) {
+            feed_reserve(feed, P.next, P.n, reserve, lane);
+            if (!feed.drained) {
+                const uint32_t available = feed.end - feed.next;
+                const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (!busy && rank < available) {
+                    slot = feed.next + rank;
+                    const uint32_t word = P.stage[slot];
+                    if ((word & WF_STAGE_MASK) == ST_TRAV) {
+                        const float4* G = reinterpret_cast<const float4*>(P.groups);
+                        const float4 g4 = G[4 * n + slot], g5 = G[5 * n + slot];
+                        t.o = xyz(g4), t.d = xyz(g5);
+                        t.limit = g4.w;
+                        t.shadow = (word & WF_SHADOW) != 0;
+                        t.closest = PYR_INF, t.shape = PYR_HIT_NONE, t.u = t.v = 0.0f; // trav_begin's start without planes
+                        if (S.num_planes != 0) {
+                            const float4 g6 = G[6 * n + slot];
+                            t.closest = g6.x, t.shape = __float_as_uint(g6.y), t.u = g6.z, t.v = g6.w;
+                        }
+                        trav_restart(t);
+                        busy = true;
+                    }
+                }
+                feed.next += min((uint32_t)idle, available);
+            }
+        }
+        if (__ballot(busy) == 0) {
+            if (feed.drained) break;
+            continue;
+        }
+        for (int step = 0; step < kSteps; ++step) {
+            if (busy && trav_step<COUNT>(view, t, stack, cnt)) {
+                if (!t.shadow) reinterpret_cast<float4*>(P.groups)[6 * n + slot] = make_float4(t.closest, __uint_as_float(t.shape), t.u, t.v);
+                P.stage[slot] = t.shadow ? (ST_NEE | WF_SHADOW | (t.blocked ? WF_BLOCKED : 0u)) : ST_SHADE;
+                busy = false;
+            }
+        }
+    }
+    flush_counters<COUNT>(cnt, counters);
 }
 
 // ------------------------------------------------------------------------------------------------ film development
@@ -1799,8 +2148,16 @@ int launch_develop(const DevelopLaunch& launch, void* stream) {
 // ------------------------------------------------------------------------------------------------ launchers
 constexpr size_t kLdsSceneBytes = 8 * 1024; // nodes + primitives staged in LDS when they fit (C1, C2: < 3 KB)
 static bool scene_fits_lds(const DevScene& scene) { return (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48 <= kLdsSceneBytes; }
+// Levels of the traversal stack kept in LDS. The synchronous walk keeps the whole stack there (its scenes are shallow);
+// the resumable walk keeps kShortStack levels (PYRITE_LDS_STACK overrides) and spills deeper ones to scratch (TravStack).
+constexpr uint32_t kShortStack = 12;
+static uint32_t short_stack_levels(const DevScene& scene) {
+    const char* e = std::getenv("PYRITE_LDS_STACK");
+    uint32_t levels = e && *e ? (uint32_t)std::strtoul(e, nullptr, 10) : kShortStack;
+    return std::max(1u, std::min(levels, scene.stack_depth));
+}
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
-    size_t bytes = (size_t)(3 * launch.spectrum_samples + scene.stack_depth) * BLOCK * sizeof(float);
+    size_t bytes = (size_t)(3 * launch.spectrum_samples + launch.stack_lds) * BLOCK * sizeof(float);
     if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
     bytes += (size_t)scene.lds_table_floats * sizeof(float);
     return bytes;
@@ -1819,7 +2176,13 @@ static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool l
 
 bool scene_is_lds_resident(const DevScene& scene) { return scene_fits_lds(scene); }
 
-int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus) {
+int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool with_counters, void* stream, int num_cus) {
+    if (scene.stack_depth > kMaxStackDepth) {
+        g_kernel_error = "BVH deeper than kMaxStackDepth";
+        return PYR_ERR_UNSUPPORTED;
+    }
+    RenderLaunch launch = launch_in;
+    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene) : scene.stack_depth;
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
@@ -1857,7 +2220,12 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
 
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream) {
     if (launch.n == 0) return PYR_OK;
-    const size_t lds = (size_t)scene.stack_depth * BLOCK * sizeof(int);
+    if (scene.stack_depth > kMaxStackDepth) {
+        g_kernel_error = "BVH deeper than kMaxStackDepth";
+        return PYR_ERR_UNSUPPORTED;
+    }
+    const uint32_t stack_lds = short_stack_levels(scene);
+    const size_t lds = (size_t)stack_lds * BLOCK * sizeof(int);
     auto kernel = with_counters ? intersect_kernel<true> : intersect_kernel<false>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
@@ -1870,6 +2238,7 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
     uint32_t needed = (launch.n + BLOCK - 1) / BLOCK;
     if (grid > needed) grid = needed;
     IntersectLaunch sized = launch;
+    sized.stack_lds = stack_lds;
     // reservation per atomic: about a quarter of a wave's share of the batch, a multiple of 64, at most 2048
     const uint32_t waves = grid * (BLOCK / 64);
     sized.reserve = std::max<uint32_t>(64, std::min<uint32_t>(2048, (launch.n / std::max<uint32_t>(waves * 4, 1)) & ~63u));
@@ -1882,4 +2251,76 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
     return PYR_OK;
 }
 
+int launch_wavefront(const DevScene& scene, const RenderLaunch& launch_in, bool with_counters, void* stream_, int num_cus, const WfPool& pool,
+                     volatile uint32_t* host_flag) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (scene.stack_depth > kMaxStackDepth) {
+        g_kernel_error = "BVH deeper than kMaxStackDepth";
+        return PYR_ERR_UNSUPPORTED;
+    }
+    if (launch_in.chunk_end == launch_in.chunk_begin || pool.n == 0) return PYR_OK;
+    RenderLaunch launch = launch_in;
+    launch.stack_lds = short_stack_levels(scene);
+    const bool interp = scene.needs_interpreter != 0;
+    using LogicKernel = void (*)(DevScene, RenderLaunch, WfPool);
+    static const LogicKernel logic_variants[2][2] = {{wf_logic_kernel<false, false>, wf_logic_kernel<false, true>},
+                                                     {wf_logic_kernel<true, false>, wf_logic_kernel<true, true>}};
+    LogicKernel logic = logic_variants[with_counters ? 1 : 0][interp ? 1 : 0];
+    auto trav = with_counters ? wf_trav_kernel<true> : wf_trav_kernel<false>;
+    const size_t lds_logic = (size_t)3 * launch.spectrum_samples * BLOCK * sizeof(float) + (size_t)scene.lds_table_floats * sizeof(float);
+    const size_t lds_trav = (size_t)launch.stack_lds * BLOCK * sizeof(int);
+    if (lds_logic > 160 * 1024) {
+        g_kernel_error = "spectrum_samples need more than 160 KB of LDS per workgroup";
+        return PYR_ERR_UNSUPPORTED;
+    }
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(logic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logic);
+    if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(trav), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trav);
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    const uint32_t blocks = (pool.n + BLOCK - 1) / BLOCK;
+    const int trav_blocks_per_cu = std::max(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(lds_trav, 1))));
+    const uint32_t trav_grid = std::min<uint32_t>((uint32_t)num_cus * (uint32_t)trav_blocks_per_cu, blocks);
+    const uint32_t trav_waves = trav_grid * (BLOCK / 64);
+    const uint32_t reserve = std::max<uint32_t>(64, std::min<uint32_t>(2048, (pool.n / std::max<uint32_t>(trav_waves * 4, 1)) & ~63u));
+    hipLaunchKernelGGL(wf_init_kernel, dim3(blocks), dim3(BLOCK), 0, stream, pool, launch.chunk_begin);
+    // Rounds are launched in batches; the last logic kernel of a batch reports whether any path still holds a ray.
+    constexpr int kBatch = 8;
+    // every round advances every live path by one ray, and a sample traces at most bounces + 2 * light_samples rays
+    const uint64_t chunks = launch.chunk_end - launch.chunk_begin, waves = pool.n / 64u;
+    const uint64_t max_rounds = ((chunks + waves - 1) / waves) * ((uint64_t)launch.bounces + 2ull * launch.light_samples + 2ull) + kBatch;
+    for (uint64_t round = 0;; round += kBatch) {
+        if (round > max_rounds) {
+            g_kernel_error = "wavefront render did not finish within its round bound";
+            return PYR_ERR_DEVICE;
+        }
+        for (int i = 0; i < kBatch; ++i) {
+            if (i == kBatch - 1) (void)hipMemsetAsync(pool.work_flag, 0, sizeof(uint32_t), stream);
+            hipLaunchKernelGGL(logic, dim3(blocks), dim3(BLOCK), lds_logic, stream, scene, launch, pool);
+            hipLaunchKernelGGL(trav, dim3(trav_grid), dim3(BLOCK), lds_trav, stream, scene, pool, reserve, launch.stack_lds, launch.counters);
+        }
+        err = hipMemcpyAsync((void*)host_flag, pool.work_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(stream);
+        if (err != hipSuccess) {
+            g_kernel_error = std::string("wavefront render: ") + hipGetErrorString(err);
+            return PYR_ERR_DEVICE;
+        }
+        if (*host_flag == 0) break;
+    }
+    return PYR_OK;
+}
+
 } // namespace pyr
+
+#ifdef PYR_PHASE_PROFILE
+extern "C" int pyr_debug_phase_profile(unsigned long long* out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pyr::g_phase_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pyr::g_phase_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

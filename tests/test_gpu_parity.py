@@ -85,11 +85,11 @@ def test_render_matches_the_oracle(name, gpu_lib):
         assert gcount[key] == ccount[key], key
 
 
-@pytest.mark.parametrize("scheduler", ["sync", "sm"])
+@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
 @pytest.mark.parametrize("name", ["c2_cornell", "lamps_example", "diamonds_example"])
-def test_both_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypatch):
-    """The bounce-synchronous walk and the stage-scheduled state machine are two schedules of the same per-path work: both
-    must reproduce the oracle (the library picks one per scene; PYRITE_SCHEDULER forces it)."""
+def test_all_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypatch):
+    """The bounce-synchronous walk, the stage-scheduled state machine and the wavefront pipeline are three schedules of the
+    same per-path work: all must reproduce the oracle (the library picks one per scene; PYRITE_SCHEDULER forces it)."""
     monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
     gfilm, cfilm, gcount, ccount = render_both(CASES[name](), 8, gpu_lib)
     assert_parity(gfilm, cfilm)
@@ -173,6 +173,51 @@ def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
         assert gcount[key] == ccount[key], key
     if glass:
         assert gcount["exposures"] < gcount["samples"] * 10  # dispersed paths expose the hero wavelength only
+
+
+@pytest.mark.parametrize("slots", ["64", "640", ""])
+@pytest.mark.parametrize("glass", [False, True])
+def test_wavefront_scheduler_on_a_c3_shaped_scene(glass, slots, gpu_lib, monkeypatch):
+    """The wavefront pipeline with a pool smaller than / equal to / larger than the work (every slot walks its own strided
+    sample sequence), ragged tiles, counters on."""
+    from pyrite_amd.renderer import Camera, Renderer, World
+
+    monkeypatch.setenv("PYRITE_SCHEDULER", "wf")
+    if slots:
+        monkeypatch.setenv("PYRITE_WF_SLOTS", slots)
+    project = scenes.c3_mesh_in_box(width=50, height=30, pixel_samples=3, glass=glass, bounces=20 if glass else None)
+    world = World(scenes.c3_flat(segments=64, sides=32, glass=glass))
+    r = Renderer.from_project(project["renderer"], seed=11)
+    r.tile_size = 16
+    cam = Camera.from_project(project["camera"])
+    gfilm, cfilm = r.new_film(50, 30), r.new_film(50, 30)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    gcount = r.render(gfilm, cam, world, counters=True)
+    assert_parity(gfilm, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+
+
+@pytest.mark.parametrize("levels", ["1", "3"])
+def test_short_lds_stack_spills_to_scratch_without_changing_results(levels, gpu_lib, monkeypatch):
+    """The resumable traversal keeps only a few stack levels in LDS (TravStack); force nearly every push into the scratch
+    part and check rays and film against the oracle."""
+    from pyrite_amd.renderer import Camera, Renderer, World
+
+    monkeypatch.setenv("PYRITE_LDS_STACK", levels)
+    project = scenes.c3_mesh_in_box(width=48, height=27, pixel_samples=4)
+    world = World(scenes.c3_flat(segments=96, sides=48))
+    assert world.bvh_info()["max_depth"] > 3
+    rays = random_rays(40000, 9, [-55, 0, 0], [0, 55, 54])
+    ohits, _ = oracle.OracleScene(world).intersect(rays)
+    ghits, _, _ = world.intersect(rays)
+    assert_same_hits(ohits, ghits)
+    r = Renderer.from_project(project["renderer"], seed=2)
+    cam = Camera.from_project(project["camera"])
+    gfilm, cfilm = r.new_film(48, 27), r.new_film(48, 27)
+    oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    r.render(gfilm, cam, world)
+    assert_parity(gfilm, cfilm)
 
 
 @pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example"])
