@@ -615,79 +615,80 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
     const float limit_cull = limit * 1.001f + 1.0e-3f; // +inf stays +inf
     int sp = 0;
     int node = 0;
+    // Every turn of the loop is one inner-node visit or ONE primitive of a leaf (the leaf code in `node` shrinks), so lanes at
+    // inner nodes do not wait for the fullest leaf of the wave (C2: 585 -> 717 Msamples/s). Letting the wave run only the
+    // kind of step most lanes wait for (the minority keeps its place) was slower on C2: 636.
     for (;;) {
-        const float4 n0 = nodes[4 * node + 0], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
-        if (COUNT) cnt.box_tests += 2;
-        float e0 = slab(mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z), o, inv);
-        float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), o, inv);
-        bool h0, h1;
-        if (SHADOW) {
-            // A box can be skipped only if nothing in it can block. Its computed entry distance and a primitive's computed
-            // hit distance are independent roundings of (at best) the same number -- for a zero-thickness box they differ
-            // by ulps either way -- so the cut-off keeps a 0.1 % margin over the blocking limit instead of comparing against
-            // it exactly (found on C3: at scene scale 50, d^2 ~ 2500 has an ulp of 2.4e-4 > DIST_EPSILON and an exact
-            // comparison skipped lamp triangles the reference tests).
-            h0 = e0 >= 0.0f && e0 * e0 < limit_cull;
-            h1 = e1 >= 0.0f && e1 * e1 < limit_cull;
-        } else {
-            h0 = e0 >= 0.0f && e0 < closest; // bvh.rs:213: skip when distance >= max_distance
-            h1 = e1 >= 0.0f && e1 < closest;
+        if (node >= 0) {
+            const float4 n0 = nodes[4 * node + 0], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
+            if (COUNT) cnt.box_tests += 2;
+            float e0 = slab(mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z), o, inv);
+            float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), o, inv);
+            bool h0, h1;
+            if (SHADOW) {
+                // A box can be skipped only if nothing in it can block. Its computed entry distance and a primitive's computed
+                // hit distance are independent roundings of (at best) the same number -- for a zero-thickness box they differ
+                // by ulps either way -- so the cut-off keeps a 0.1 % margin over the blocking limit instead of comparing against
+                // it exactly (found on C3: at scene scale 50, d^2 ~ 2500 has an ulp of 2.4e-4 > DIST_EPSILON and an exact
+                // comparison skipped lamp triangles the reference tests).
+                h0 = e0 >= 0.0f && e0 * e0 < limit_cull;
+                h1 = e1 >= 0.0f && e1 * e1 < limit_cull;
+            } else {
+                h0 = e0 >= 0.0f && e0 < closest; // bvh.rs:213: skip when distance >= max_distance
+                h1 = e1 >= 0.0f && e1 < closest;
+            }
+            const int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+            if (h0 && h1) {
+                bool swap = e1 < e0;
+                node = swap ? c1 : c0;
+                stack[sp * BLOCK] = swap ? c0 : c1;
+                sp++;
+            } else if (h0) {
+                node = c0;
+            } else if (h1) {
+                node = c1;
+            } else {
+                if (sp == 0) break;
+                sp--;
+                node = stack[sp * BLOCK];
+            }
+            continue;
         }
-        const int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
-        int next;
-        if (h0 && h1) {
-            bool swap = e1 < e0;
-            next = swap ? c1 : c0;
-            stack[sp * BLOCK] = swap ? c0 : c1;
-            sp++;
-        } else if (h0) {
-            next = c0;
-        } else if (h1) {
-            next = c1;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            next = stack[sp * BLOCK];
-        }
-        bool done = false;
-        while (next < 0) {
-            uint32_t code = (uint32_t)(-1 - next);
-            uint32_t first = code >> 3, count = code & 7u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4 a = prims[3 * (first + k) + 0], b = prims[3 * (first + k) + 1];
-                const uint32_t shape = __float_as_uint(a.w);
-                float dist, u = 0.0f, v = 0.0f;
-                bool ok;
-                if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
-                    const float4 c = prims[3 * (first + k) + 2];
-                    if (COUNT) cnt.triangle_tests++;
-                    ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, dist, u, v);
-                } else {
-                    f3 point;
-                    if (COUNT) cnt.sphere_tests++;
-                    ok = sphere_test(mk(a.x, a.y, a.z), b.x, o, d, dist, point);
-                }
-                if (ok) {
-                    if (SHADOW) {
-                        if (dist > DIST_EPSILON && dist * dist < limit) return true;
-                    } else if (dist > DIST_EPSILON && dist < closest) {
-                        closest = dist;
-                        hit.t = dist;
-                        hit.shape = shape;
-                        hit.u = u;
-                        hit.v = v;
-                    }
+        const uint32_t code = (uint32_t)(-1 - node);
+        const uint32_t first = code >> 3, count = code & 7u;
+        if (count != 0) {
+            const float4 a = prims[3 * first + 0], b = prims[3 * first + 1];
+            const uint32_t shape = __float_as_uint(a.w);
+            float dist, u = 0.0f, v = 0.0f;
+            bool ok;
+            if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
+                const float4 c = prims[3 * first + 2];
+                if (COUNT) cnt.triangle_tests++;
+                ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), o, d, dist, u, v);
+            } else {
+                f3 point;
+                if (COUNT) cnt.sphere_tests++;
+                ok = sphere_test(mk(a.x, a.y, a.z), b.x, o, d, dist, point);
+            }
+            if (ok) {
+                if (SHADOW) {
+                    if (dist > DIST_EPSILON && dist * dist < limit) return true;
+                } else if (dist > DIST_EPSILON && dist < closest) {
+                    closest = dist;
+                    hit.t = dist;
+                    hit.shape = shape;
+                    hit.u = u;
+                    hit.v = v;
                 }
             }
-            if (sp == 0) {
-                done = true;
-                break;
+            if (count > 1) {
+                node = -1 - (int)(((first + 1) << 3) | (count - 1));
+                continue;
             }
-            sp--;
-            next = stack[sp * BLOCK];
         }
-        if (done) break;
-        node = next;
+        if (sp == 0) break;
+        sp--;
+        node = stack[sp * BLOCK];
     }
     return hit.shape != PYR_HIT_NONE;
 }
@@ -1426,6 +1427,26 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
     return false;
 }
 
+// One step for the lanes of a wave that have a ray in flight (`active`), with a vote: a step is an inner-node visit or a
+// primitive test, two different pieces of code, and a wave whose lanes want both runs both at partial occupancy. When fewer
+// than PYR_VOTE_BOTH lanes want the minority kind, only the majority kind runs this turn and the minority keeps its place
+// (rays are independent; they are served by a later turn). Must be called by every lane of the wave. Measured on C3
+// (intersect Mrays/s | stage-scheduled render Msamples/s): both kinds every turn 5774 | 210; minority runs too when it
+// has >= 16 lanes 5899 | 225; >= 32 lanes 5882 | 228; majority only (65) 6087 | 236.
+#ifndef PYR_VOTE_BOTH
+#define PYR_VOTE_BOTH 65
+#endif
+template <bool COUNT>
+DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
+    if (PYR_VOTE_BOTH > 0) {
+        const int want_node = __popcll(__ballot(active && t.node >= 0)), want_leaf = __popcll(__ballot(active && t.node < 0));
+        const bool run_node = want_node >= want_leaf || want_node >= PYR_VOTE_BOTH;
+        const bool run_leaf = want_leaf > want_node || want_leaf >= PYR_VOTE_BOTH;
+        if (active && !(t.node >= 0 ? run_node : run_leaf)) active = false;
+    }
+    return active && trav_step<COUNT>(view, t, stack, cnt);
+}
+
 // Per-path state of the resumable integrator and the code of its phases; shared by the stage-scheduled kernel (state in
 // registers) and the wavefront kernels (state in HBM between phases).
 template <bool COUNT, bool INTERP>
@@ -1729,9 +1750,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
 #endif
             for (int step = 0; step < trav_steps; ++step) {
                 PROF_LANES(3, w.stage == ST_TRAV);
-                if (w.stage == ST_TRAV) {
-                    if (trav_step<COUNT>(view, w.t, stack, cnt)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
-                }
+                if (trav_step_voted<COUNT>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
             }
             PROF_END(3);
         }
@@ -1813,7 +1832,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
             continue;
         }
         for (int step = 0; step < kSteps; ++step) {
-            if (busy && trav_step<COUNT>(view, t, stack, cnt)) {
+            if (trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
                 PyrHit out;
                 out.distance = t.shape != PYR_HIT_NONE ? t.closest : PYR_INF;
                 out.shape = t.shape;
@@ -2048,7 +2067,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
             continue;
         }
         for (int step = 0; step < kSteps; ++step) {
-            if (busy && trav_step<COUNT>(view, t, stack, cnt)) {
+            if (trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
                 if (!t.shadow) reinterpret_cast<float4*>(P.groups)[6 * n + slot] = make_float4(t.closest, __uint_as_float(t.shape), t.u, t.v);
                 P.stage[slot] = t.shadow ? (ST_NEE | WF_SHADOW | (t.blocked ? WF_BLOCKED : 0u)) : ST_SHADE;
                 busy = false;
@@ -2148,12 +2167,21 @@ int launch_develop(const DevelopLaunch& launch, void* stream) {
 // ------------------------------------------------------------------------------------------------ launchers
 constexpr size_t kLdsSceneBytes = 8 * 1024; // nodes + primitives staged in LDS when they fit (C1, C2: < 3 KB)
 static bool scene_fits_lds(const DevScene& scene) { return (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48 <= kLdsSceneBytes; }
-// Levels of the traversal stack kept in LDS. The synchronous walk keeps the whole stack there (its scenes are shallow);
-// the resumable walk keeps kShortStack levels (PYRITE_LDS_STACK overrides) and spills deeper ones to scratch (TravStack).
-constexpr uint32_t kShortStack = 12;
-static uint32_t short_stack_levels(const DevScene& scene) {
+// Levels of the traversal stack kept in LDS. The synchronous walk keeps the whole stack there (its scenes are shallow). The
+// resumable walk spills deeper levels to scratch (TravStack) and keeps as many levels in LDS as still let `workgroups`
+// workgroups share a CU's 160 KB next to `other_bytes` of LDS each -- on C3 the render runs at 103 / 135 / 160 Msamples/s
+// with 2 / 3 / 4 workgroups per CU and does not care whether 4 or 12 levels are in LDS. PYRITE_LDS_STACK overrides.
+constexpr uint32_t kShortStackMax = 16;
+static uint32_t short_stack_levels(const DevScene& scene, size_t other_bytes, uint32_t workgroups) {
     const char* e = std::getenv("PYRITE_LDS_STACK");
-    uint32_t levels = e && *e ? (uint32_t)std::strtoul(e, nullptr, 10) : kShortStack;
+    uint32_t levels;
+    if (e && *e) {
+        levels = (uint32_t)std::strtoul(e, nullptr, 10);
+    } else {
+        const size_t budget = (160 * 1024) / std::max(workgroups, 1u);
+        levels = budget > other_bytes ? (uint32_t)((budget - other_bytes) / (BLOCK * sizeof(int))) : 0u;
+        levels = std::min(levels, kShortStackMax);
+    }
     return std::max(1u, std::min(levels, scene.stack_depth));
 }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
@@ -2182,7 +2210,9 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
         return PYR_ERR_UNSUPPORTED;
     }
     RenderLaunch launch = launch_in;
-    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene) : scene.stack_depth;
+    launch.stack_lds = 0;
+    // the stage-scheduled kernel is built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
+    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), 4) : scene.stack_depth;
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
@@ -2224,7 +2254,7 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
         g_kernel_error = "BVH deeper than kMaxStackDepth";
         return PYR_ERR_UNSUPPORTED;
     }
-    const uint32_t stack_lds = short_stack_levels(scene);
+    const uint32_t stack_lds = short_stack_levels(scene, 0, 8);
     const size_t lds = (size_t)stack_lds * BLOCK * sizeof(int);
     auto kernel = with_counters ? intersect_kernel<true> : intersect_kernel<false>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2260,7 +2290,7 @@ int launch_wavefront(const DevScene& scene, const RenderLaunch& launch_in, bool 
     }
     if (launch_in.chunk_end == launch_in.chunk_begin || pool.n == 0) return PYR_OK;
     RenderLaunch launch = launch_in;
-    launch.stack_lds = short_stack_levels(scene);
+    launch.stack_lds = short_stack_levels(scene, 0, 8);
     const bool interp = scene.needs_interpreter != 0;
     using LogicKernel = void (*)(DevScene, RenderLaunch, WfPool);
     static const LogicKernel logic_variants[2][2] = {{wf_logic_kernel<false, false>, wf_logic_kernel<false, true>},
