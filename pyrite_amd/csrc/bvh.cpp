@@ -61,29 +61,27 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
         refs[i].shape = prims[i].shape;
     }
 
+    // Padding of every stored box: 16 ulps of the largest coordinate in the scene. The kernels compute slab distances as
+    // fma(bound, 1/d, -(o * 1/d)), whose error is half an ulp of |o / d| -- in world units half an ulp of the ray origin,
+    // which lies inside the scene -- so a padded box is never missed by a ray that hits something inside the exact box.
+    float max_abs = 0.0f;
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) max_abs = std::max(max_abs, std::max(std::fabs(prims[i].lo[a]), std::fabs(prims[i].hi[a])));
+    const float pad = 16.0f * 1.1920929e-7f * max_abs;
+
     auto set_child = [&](int32_t parent, int slot, int32_t code, const Box& box) {
         Node64& p = out.nodes[parent];
-        if (slot == 0) {
-            p.child0 = code;
-            for (int a = 0; a < 3; ++a) {
-                p.lo0[a] = box.lo[a];
-                p.hi0[a] = box.hi[a];
-            }
-        } else {
-            p.child1 = code;
-            for (int a = 0; a < 3; ++a) {
-                p.lo1[a] = box.lo[a];
-                p.hi1[a] = box.hi[a];
-            }
-        }
+        p.child[slot] = code;
+        p.lo_x[slot] = box.lo[0] - pad, p.lo_y[slot] = box.lo[1] - pad, p.lo_z[slot] = box.lo[2] - pad;
+        p.hi_x[slot] = box.hi[0] + pad, p.hi_y[slot] = box.hi[1] + pad, p.hi_z[slot] = box.hi[2] + pad;
     };
     auto empty_node = []() {
         Node64 nd{};
-        for (int a = 0; a < 3; ++a) {
-            nd.lo0[a] = nd.lo1[a] = kInf; // an empty child never passes the slab test
-            nd.hi0[a] = nd.hi1[a] = -kInf;
+        for (int c = 0; c < 2; ++c) {
+            nd.lo_x[c] = nd.lo_y[c] = nd.lo_z[c] = kInf; // an empty child leads to an empty leaf at worst
+            nd.hi_x[c] = nd.hi_y[c] = nd.hi_z[c] = -kInf;
+            nd.child[c] = encode_leaf(0, 0);
         }
-        nd.child0 = nd.child1 = encode_leaf(0, 0);
         return nd;
     };
 

@@ -18,16 +18,16 @@ struct PrimBounds {
     uint32_t shape; // (PyrShapeKind << 30) | index
 };
 
-// Two-child node, 64 bytes, read by the kernels as four float4.
+// Two-child node, 64 bytes, read by the kernels as four float4. The two children's bounds are interleaved so that each
+// float4 holds two (child 0, child 1) pairs: the kernels test both boxes with packed-fp32 instructions (v_pk_fma_f32) and a
+// pair must sit in an aligned register pair. Boxes are padded by a few ulps of the scene's extent at build time
+// (build_bvh), which makes the kernels' `t = bound * inv - origin * inv` form of the slab test conservative.
 struct alignas(64) Node64 {
-    float lo0[3];
-    int32_t child0; // >= 0: node index; < 0: leaf, -1 - ((first_prim << 3) | count), count 0..4 (0 = empty)
-    float hi0[3];
-    int32_t child1;
-    float lo1[3];
-    uint32_t pad0;
-    float hi1[3];
-    uint32_t pad1;
+    float lo_x[2], lo_y[2]; // [child]
+    float lo_z[2], hi_x[2];
+    float hi_y[2], hi_z[2];
+    int32_t child[2]; // >= 0: node index; < 0: leaf, -1 - ((first_prim << 3) | count), count 0..4 (0 = empty)
+    uint32_t pad[2];
 };
 static_assert(sizeof(Node64) == 64, "node must be 64 bytes");
 

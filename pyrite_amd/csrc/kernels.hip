@@ -586,6 +586,27 @@ DEV float slab(f3 lo, f3 hi, f3 o, f3 inv) {
     return (tmax >= tmin && tmax >= 0.0f) ? fmaxf(tmin, 0.0f) : -1.0f;
 }
 
+// Both children of a node at once. The node stores the bounds interleaved (bvh.h Node64: q0 = lo.x lo.y, q1 = lo.z hi.x,
+// q2 = hi.y hi.z, each as a (child 0, child 1) pair), so the twelve plane distances are six v_pk_fma_f32:
+// t = bound * inv - o * inv. That form rounds differently from math.rs:184-207's (bound - o) * inv; the boxes are this
+// library's own and are padded at build time so that the test stays conservative (bvh.cpp), and NaN (0 * inf on a ray
+// parallel to a slab) drops out of min / max as it does in the reference's f32::min / max.
+typedef float f2v __attribute__((ext_vector_type(2)));
+DEV void slab_pair(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 inv, float& e0, float& e1) {
+    const f2v ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const float ox = -(o.x * inv.x), oy = -(o.y * inv.y), oz = -(o.z * inv.z);
+    const f2v nox = {ox, ox}, noy = {oy, oy}, noz = {oz, oz};
+    const f2v lx = __builtin_elementwise_fma((f2v){q0.x, q0.y}, ix, nox), hx = __builtin_elementwise_fma((f2v){q1.z, q1.w}, ix, nox);
+    const f2v ly = __builtin_elementwise_fma((f2v){q0.z, q0.w}, iy, noy), hy = __builtin_elementwise_fma((f2v){q2.x, q2.y}, iy, noy);
+    const f2v lz = __builtin_elementwise_fma((f2v){q1.x, q1.y}, iz, noz), hz = __builtin_elementwise_fma((f2v){q2.z, q2.w}, iz, noz);
+    const float tmin0 = fmaxf(fmaxf(fminf(lx.x, hx.x), fminf(ly.x, hy.x)), fminf(lz.x, hz.x));
+    const float tmax0 = fminf(fminf(fmaxf(lx.x, hx.x), fmaxf(ly.x, hy.x)), fmaxf(lz.x, hz.x));
+    const float tmin1 = fmaxf(fmaxf(fminf(lx.y, hx.y), fminf(ly.y, hy.y)), fminf(lz.y, hz.y));
+    const float tmax1 = fminf(fminf(fmaxf(lx.y, hx.y), fmaxf(ly.y, hy.y)), fmaxf(lz.y, hz.y));
+    e0 = (tmax0 >= tmin0 && tmax0 >= 0.0f) ? fmaxf(tmin0, 0.0f) : -1.0f;
+    e1 = (tmax1 >= tmin1 && tmax1 >= 0.0f) ? fmaxf(tmin1, 0.0f) : -1.0f;
+}
+
 // World::intersect (world.rs:273-299). SHADOW = false: closest hit with DIST_EPSILON < d < closest.
 // SHADOW = true: answers trace_direct's visibility question (tracer.rs:381-389) -- "is there a hit with
 // d > eps and d*d < limit" -- and returns as soon as one is found (equivalent to testing the closest hit, because
@@ -622,8 +643,8 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
         if (node >= 0) {
             const float4 n0 = nodes[4 * node + 0], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
             if (COUNT) cnt.box_tests += 2;
-            float e0 = slab(mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z), o, inv);
-            float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), o, inv);
+            float e0, e1;
+            slab_pair(n0, n1, n2, o, inv, e0, e1);
             bool h0, h1;
             if (SHADOW) {
                 // A box can be skipped only if nothing in it can block. Its computed entry distance and a primitive's computed
@@ -637,7 +658,7 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
                 h0 = e0 >= 0.0f && e0 < closest; // bvh.rs:213: skip when distance >= max_distance
                 h1 = e1 >= 0.0f && e1 < closest;
             }
-            const int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (h0 && h1) {
                 bool swap = e1 < e0;
                 node = swap ? c1 : c0;
@@ -1357,8 +1378,8 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
         const float4* nd = view.nodes + 4 * t.node;
         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
         if (COUNT) cnt.box_tests += 2;
-        const float e0 = slab(mk(n0.x, n0.y, n0.z), mk(n1.x, n1.y, n1.z), t.o, t.inv);
-        const float e1 = slab(mk(n2.x, n2.y, n2.z), mk(n3.x, n3.y, n3.z), t.o, t.inv);
+        float e0, e1;
+        slab_pair(n0, n1, n2, t.o, t.inv, e0, e1);
         bool h0, h1;
         if (t.shadow) {
             h0 = e0 >= 0.0f && e0 * e0 < t.limit_cull;
@@ -1367,7 +1388,7 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
             h0 = e0 >= 0.0f && e0 < t.closest;
             h1 = e1 >= 0.0f && e1 < t.closest;
         }
-        const int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
         if (h0 && h1) {
             const bool swap = e1 < e0;
             t.node = swap ? c1 : c0;
