@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PYR_ABI_VERSION 1
+#define PYR_ABI_VERSION 2
 
 typedef enum PyrStatus {
     PYR_OK = 0,
@@ -110,8 +110,8 @@ typedef enum PyrOp {
     PYR_OP_VECTOR = 1,        /* VectorValue     {x,y,z,w, output}                           :24-30 */
     PYR_OP_RGB = 2,           /* RgbValue        {red=x, green=y, blue=z, output}            :31-36 */
     PYR_OP_SPECTRUM = 3,      /* SpectrumValue   {wavelength=x, spectrum=a, output}          :37-41 */
-    PYR_OP_COLOR_TEXTURE = 4, /* ColorTextureValue -- PYR_ERR_UNSUPPORTED                    :42-46 */
-    PYR_OP_MONO_TEXTURE = 5,  /* MonoTextureValue  -- PYR_ERR_UNSUPPORTED                    :47-51 */
+    PYR_OP_COLOR_TEXTURE = 4, /* ColorTextureValue {texture_coordinates=b (vector input), texture=a, output (rgb)} :42-46 */
+    PYR_OP_MONO_TEXTURE = 5,  /* MonoTextureValue  {texture_coordinates=b (vector input), texture=a, output (number)} :47-51 */
     PYR_OP_RGB_SPECTRUM = 6,  /* RgbSpectrumValue{wavelength=x, source=a (rgb reg), output}  :52-56 */
     PYR_OP_FRESNEL = 7,       /* Fresnel {ior=x, env_ior=y, normal=a, incident=b (vector inputs), output} :57-63 */
     PYR_OP_BLACKBODY = 8,     /* Blackbody {wavelength=x, temperature=y, output}             :64-68 */
@@ -205,8 +205,18 @@ typedef struct PyrMaterial {
     uint32_t num_components;
     uint32_t first_emissive;
     uint32_t num_emissive;
-    int32_t normal_map_program; /* -1 = None; anything else is PYR_ERR_UNSUPPORTED in this round */
+    int32_t normal_map_program; /* -1 = None; else a program with vector output run on NormalInput (materials/mod.rs:68-80) */
 } PyrMaterial;
+
+/* Texture<LinSrgba> / Texture<LinLuma> (texture.rs:18-22): linearised texels, row-major from the top row of the image
+ * (texture.rs:163: data[x + y * width]). Color textures hold (red, green, blue, alpha), mono textures one luma value. */
+typedef enum PyrTextureFormat { PYR_TEXTURE_COLOR = 0, PYR_TEXTURE_MONO = 1 } PyrTextureFormat;
+typedef struct PyrTexture {
+    uint32_t format; /* PyrTextureFormat */
+    uint32_t width, height;
+    uint32_t reserved;
+    uint64_t offset; /* first texel's float in PyrSceneDesc.texture_data */
+} PyrTexture;
 
 /* Lamp (lamp.rs:12-20). */
 typedef enum PyrLampKind { PYR_LAMP_DIRECTIONAL = 0, PYR_LAMP_POINT = 1, PYR_LAMP_SHAPE = 2 } PyrLampKind;
@@ -269,6 +279,19 @@ typedef struct PyrSceneDesc {
     float rgb_basis_max;
 
     uint32_t sky_program; /* World::sky */
+
+    /* Resources.textures (project/textures.rs:13-16); PYR_OP_COLOR_TEXTURE / PYR_OP_MONO_TEXTURE index this one list. */
+    uint32_t num_textures;
+    const PyrTexture* textures;
+    uint64_t num_texture_floats;
+    const float* texture_data;
+
+    /* Normal::from_space (shapes/mod.rs:531-535), the tangent-space rotation as a quaternion (s, x, y, z), after
+     * make_triangle (world.rs:308-374) and Shape::transform (shapes/mod.rs:322-344). Needed for triangles whose material
+     * has a normal map (NULL: identity) and for every plane (texture coordinates come from it, shapes/mod.rs:454-468;
+     * NULL: derived from the plane normal as world.rs:88-100 does). Sphere frames are computed at the hit. */
+    const float* tri_frames;   /* [num_triangles][3][4] or NULL */
+    const float* plane_frames; /* [num_planes][4] or NULL */
 } PyrSceneDesc;
 
 typedef struct PyrScene PyrScene;

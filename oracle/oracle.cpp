@@ -137,6 +137,51 @@ inline V3 normalize_to(V3 a, float m) { return a * (m / magnitude(a)); }
 inline V3 normalize(V3 a) { return normalize_to(a, 1.0f); }
 inline float axis(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
+// [3P] cgmath 0.17 Quaternion {s, v}: the operations Normal uses (shapes/mod.rs:531-584), restated from the published
+// source: From<Matrix3> (the trace / largest-diagonal branches of quaternion.rs), component-wise + and * f32, normalize via
+// InnerSpace::normalize_to, Mul<Vector3> = (v x (v x vec + vec * s)) * 2 + vec, conjugate.
+struct Quat {
+    float s, x, y, z;
+};
+inline Quat quat_scale(Quat q, float f) { return Quat{q.s * f, q.x * f, q.y * f, q.z * f}; }
+inline Quat quat_add(Quat a, Quat b) { return Quat{a.s + b.s, a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Quat quat_normalize(Quat q) {
+    float m = std::sqrt(q.s * q.s + q.x * q.x + q.y * q.y + q.z * q.z); // dot: s*s + v.dot(v) [3P]
+    return quat_scale(q, 1.0f / m);
+}
+inline Quat quat_conjugate(Quat q) { return Quat{q.s, -q.x, -q.y, -q.z}; }
+inline V3 quat_rotate(Quat q, V3 vec) {
+    V3 v = v3(q.x, q.y, q.z);
+    V3 tmp = cross(v, vec) + vec * q.s;
+    return cross(v, tmp) * 2.0f + vec;
+}
+// Matrix3::from_cols(c0, c1, c2).into(): m[c][r] is column c, row r.
+inline Quat quat_from_cols(V3 c0, V3 c1, V3 c2) {
+    const float m00 = c0.x, m01 = c0.y, m02 = c0.z, m10 = c1.x, m11 = c1.y, m12 = c1.z, m20 = c2.x, m21 = c2.y, m22 = c2.z;
+    float trace = m00 + m11 + m22;
+    if (trace >= 0.0f) {
+        float s = std::sqrt(1.0f + trace);
+        float w = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{w, (m12 - m21) * s, (m20 - m02) * s, (m01 - m10) * s};
+    } else if (m00 > m11 && m00 > m22) {
+        float s = std::sqrt((m00 - m11 - m22) + 1.0f);
+        float x = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{(m12 - m21) * s, x, (m10 + m01) * s, (m02 + m20) * s};
+    } else if (m11 > m22) {
+        float s = std::sqrt((m11 - m00 - m22) + 1.0f);
+        float y = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{(m20 - m02) * s, (m10 + m01) * s, y, (m21 + m12) * s};
+    } else {
+        float s = std::sqrt((m22 - m00 - m11) + 1.0f);
+        float z = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{(m01 - m10) * s, (m02 + m20) * s, (m21 + m12) * s, z};
+    }
+}
+
 struct Ray {
     V3 origin, direction;
 };
@@ -400,6 +445,7 @@ struct Triangle { // Shape::Triangle, shapes/mod.rs:39-46
     float t1[2], t2[2], t3[2];
     V3 edge1, edge2;
     uint32_t material;
+    Quat f1, f2, f3; // Vertex.normal.from_space
 };
 struct Sphere { // Shape::Sphere, shapes/mod.rs:33-38
     V3 position;
@@ -411,6 +457,11 @@ struct Plane { // shapes::Plane, shapes/mod.rs:434-439 ([3P] collision::Plane {n
     V3 origin, normal;
     float tex_scale[2];
     uint32_t material;
+    Quat frame; // normal.from_space
+};
+struct Texture { // texture.rs:18-22; channels = 4 (LinSrgba) or 1 (LinLuma)
+    uint32_t width, height, channels;
+    const float* data;
 };
 
 struct ShapeRef { // &Shape
@@ -431,8 +482,9 @@ struct Intersection { // shapes/mod.rs:472-482 with ShapeSurfacePoint inlined
     float u, v;
 };
 
-struct SurfaceData { // shapes/mod.rs:526-529; the tangent frame quaternion is only read by normal maps (out of scope)
+struct SurfaceData { // shapes/mod.rs:526-529 (Normal = vector + from_space, :531-535)
     V3 normal;
+    Quat from_space;
     float texture[2];
 };
 
@@ -453,6 +505,8 @@ struct OracleScene {
     float rgb_basis_min = 0, rgb_basis_max = 0;
     uint32_t sky_program = 0;
     std::vector<FlatNode> nodes; // Bvh::nodes
+    std::vector<float> texture_data;
+    std::vector<Texture> textures; // Resources.textures
 };
 
 namespace {
@@ -555,7 +609,18 @@ inline SurfaceData surface_data(const OracleScene& s, const Intersection& hit) {
         V3 normal = normalize(hit.position - sp.position);
         float latitude = acos32(normal.y);
         float longitude = atan2_32(normal.x, normal.z);
+        // Matrix3::from_angle_y(longitude) * Matrix3::from_angle_x(latitude - PI/2) [3P cgmath: columns (c,0,-s),(0,1,0),(s,0,c)
+        // and (1,0,0),(0,c,s),(0,-s,c); the product's column j is A * B.col(j), each entry a row(i).dot(col) summed x, y, z]
+        float sy = sin32(longitude), cy = cos32(longitude);
+        float ax = latitude - PI * 0.5f;
+        float sx = sin32(ax), cx = cos32(ax);
+        auto rowdot = [](float a0, float a1, float a2, V3 b) { return a0 * b.x + a1 * b.y + a2 * b.z; };
+        // A rows: (cy, 0, sy), (0, 1, 0), (-sy, 0, cy); B columns: (1,0,0), (0,cx,sx), (0,-sx,cx)
+        V3 bc[3] = {v3(1.0f, 0.0f, 0.0f), v3(0.0f, cx, sx), v3(0.0f, -sx, cx)};
+        V3 col[3];
+        for (int j = 0; j < 3; ++j) col[j] = v3(rowdot(cy, 0.0f, sy, bc[j]), rowdot(0.0f, 1.0f, 0.0f, bc[j]), rowdot(-sy, 0.0f, cy, bc[j]));
         sd.normal = normal;
+        sd.from_space = quat_from_cols(col[0], col[1], col[2]);
         sd.texture[0] = (longitude * (1.0f / PI) * 0.5f) / sp.tex_scale[0];
         sd.texture[1] = (1.0f - (latitude * (1.0f / PI))) / sp.tex_scale[1];
     } else if (hit.shape.kind == PYR_SHAPE_TRIANGLE) {
@@ -563,12 +628,16 @@ inline SurfaceData surface_data(const OracleScene& s, const Intersection& hit) {
         float u = hit.u, v = hit.v;
         float w = 1.0f - (u + v);
         sd.normal = normalize(t.n1 * w + t.n2 * u + t.n3 * v);
+        sd.from_space = quat_normalize(quat_add(quat_add(quat_scale(t.f1, w), quat_scale(t.f2, u)), quat_scale(t.f3, v))); // :552
         sd.texture[0] = t.t1[0] * w + t.t2[0] * u + t.t3[0] * v;
         sd.texture[1] = t.t1[1] * w + t.t2[1] * u + t.t3[1] * v;
     } else {
         const Plane& p = s.planes[hit.shape.index];
         sd.normal = p.normal;
-        sd.texture[0] = sd.texture[1] = 0.0f; // plane uv needs the tangent frame; only textures read it (out of scope)
+        sd.from_space = p.frame;
+        V3 normal_space = quat_rotate(quat_conjugate(p.frame), hit.position); // Normal::into_space, :568-570
+        sd.texture[0] = normal_space.x / p.tex_scale[0];
+        sd.texture[1] = normal_space.y / p.tex_scale[1];
     }
     return sd;
 }
@@ -813,6 +882,55 @@ struct ProgramInput { // RenderContext (tracer.rs:72-77) / ProbabilityInput (mat
     bool wavelength_used = false; // ProbabilityInput::wavelength_used
 };
 
+// texture.rs:297-334 (cubic_interpolate, bicubic_interpolate) on one channel; LinSrgba's +, -, * are component-wise.
+inline float cubic_interpolate(float v1, float v2, float v3_, float v4, float pos) {
+    float a = (v4 - v3_) - (v1 - v2);
+    float b = (v1 - v2) - a;
+    float c = v3_ - v1;
+    float d = v2;
+    return d + (c + (b + a * pos) * pos) * pos;
+}
+// isize::rem_euclid for a positive modulus.
+inline int64_t rem_euclid(int64_t a, int64_t m) {
+    int64_t r = a % m;
+    return r < 0 ? r + m : r;
+}
+// Texture::get_color, texture.rs:87-150: 4 x 4 texels with wrap-around, rows from the top (y flipped), bicubic.
+inline void texture_get_color(const Texture& t, float px, float py, float* out) {
+    float width_f = (float)t.width, height_f = (float)t.height;
+    float x = px * width_f - 0.5f;
+    float x_floor = std::floor(x);
+    int64_t w = t.width, h = t.height;
+    int64_t xs[4], ys[4];
+    // Rust `as isize` saturates and maps NaN to 0
+    auto to_isize = [](float f) -> int64_t {
+        if (f != f) return 0;
+        if (f >= 9.2233720368547758e18f) return INT64_MAX;
+        if (f <= -9.2233720368547758e18f) return INT64_MIN;
+        return (int64_t)f;
+    };
+    xs[1] = rem_euclid(to_isize(x_floor), w);
+    xs[0] = xs[1] == 0 ? w - 1 : xs[1] - 1;
+    xs[2] = xs[1] == w - 1 ? 0 : xs[1] + 1;
+    xs[3] = xs[2] == w - 1 ? 0 : xs[2] + 1;
+    float y = (1.0f - py) * height_f - 0.5f;
+    float y_floor = std::floor(y);
+    ys[1] = rem_euclid(to_isize(y_floor), h);
+    ys[0] = ys[1] == 0 ? h - 1 : ys[1] - 1;
+    ys[2] = ys[1] == h - 1 ? 0 : ys[1] + 1;
+    ys[3] = ys[2] == h - 1 ? 0 : ys[2] + 1;
+    float fx = x - x_floor, fy = y - y_floor;
+    for (uint32_t ch = 0; ch < t.channels; ++ch) {
+        float rows[4];
+        for (int r = 0; r < 4; ++r) {
+            float v[4];
+            for (int k = 0; k < 4; ++k) v[k] = t.data[((size_t)xs[k] + (size_t)ys[r] * t.width) * t.channels + ch];
+            rows[r] = cubic_interpolate(v[0], v[1], v[2], v[3], fx);
+        }
+        out[ch] = cubic_interpolate(rows[0], rows[1], rows[2], rows[3], fy);
+    }
+}
+
 struct Exe { // ExecutionContext, execution_context.rs:15-18 (+ Registers, registers.rs)
     const OracleScene* scene;
     std::vector<float> number;
@@ -956,7 +1074,21 @@ struct Exe { // ExecutionContext, execution_context.rs:15-18 (+ Registers, regis
                 number[ins.output] = rmax(rmin(value, mx), mn);
                 break;
             }
-            default: break; // texture opcodes are rejected at scene creation
+            case PYR_OP_COLOR_TEXTURE: { // :114-126
+                V4 pos = vector_value(ins.b, in);
+                float c[4];
+                texture_get_color(s.textures[ins.a], pos.x, pos.y, c);
+                rgb[ins.output] = V4{c[0], c[1], c[2], c[3]};
+                break;
+            }
+            case PYR_OP_MONO_TEXTURE: { // :127-139
+                V4 pos = vector_value(ins.b, in);
+                float c[1];
+                texture_get_color(s.textures[ins.a], pos.x, pos.y, c);
+                number[ins.output] = c[0];
+                break;
+            }
+            default: break;
             }
         }
     }
@@ -964,6 +1096,17 @@ struct Exe { // ExecutionContext, execution_context.rs:15-18 (+ Registers, regis
     float output(const PyrProgram& p) {
         if (p.output_kind == PYR_OUTPUT_NUMBER) return number[p.output_reg];
         return vector[p.output_reg].x; // f32 programs never read a vector register (compiler.rs:561-563)
+    }
+
+    // ExecutionContext::run for a Vector program (normal maps): a constant program is a number broadcast (compiler.rs).
+    V4 run_vector(uint32_t program, ProgramInput& in) {
+        const PyrProgram& p = scene->programs[program];
+        if (p.kind == PYR_PROGRAM_CONSTANT) return V4{p.constant, p.constant, p.constant, p.constant};
+        reserve(p);
+        run_instructions(p, in, 0xFFu);
+        if (p.output_kind == PYR_OUTPUT_VECTOR) return vector[p.output_reg];
+        float n = number[p.output_reg];
+        return V4{n, n, n, n};
     }
 
     // ExecutionContext::run, execution_context.rs:29-56.
@@ -1340,7 +1483,12 @@ void trace(const OracleScene& s, std::vector<Bounce>& path, Rng& rng, Ray ray, f
             c.shaded_hits++;
             const PyrMaterial& material = s.materials[shape_material(s, hit.shape)];
             SurfaceData sd = surface_data(s, hit);
-            V3 normal = sd.normal; // apply_normal_map with normal_map == None, materials/mod.rs:77-79
+            V3 normal = sd.normal;
+            if (material.normal_map_program >= 0) { // Material::apply_normal_map, materials/mod.rs:68-80 (tracer.rs:227-232)
+                ProgramInput normal_input{wavelength, sd.normal, ray.direction, {sd.texture[0], sd.texture[1]}};
+                V4 n = exe.run_vector((uint32_t)material.normal_map_program, normal_input);
+                normal = normalize(quat_rotate(sd.from_space, v3(n.x, n.y, n.z)));
+            }
             V3 position = hit.position;
             // Material::choose_component, materials/mod.rs:48-54
             uint32_t pick = choose_index(rng, material.num_components);
@@ -1653,12 +1801,24 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
 int validate_desc(const PyrSceneDesc* d) {
     if (!d) return fail(PYR_ERR_INVALID_ARGUMENT, "null scene description");
     if (d->sky_program >= d->num_programs) return fail(PYR_ERR_INVALID_ARGUMENT, "sky program out of range");
-    for (uint32_t i = 0; i < d->num_instrs; ++i)
-        if (d->instrs[i].op == PYR_OP_COLOR_TEXTURE || d->instrs[i].op == PYR_OP_MONO_TEXTURE)
-            return fail(PYR_ERR_UNSUPPORTED, "texture opcodes are out of scope");
+    for (uint32_t i = 0; i < d->num_instrs; ++i) {
+        const PyrInstr& ins = d->instrs[i];
+        if (ins.op == PYR_OP_COLOR_TEXTURE || ins.op == PYR_OP_MONO_TEXTURE) {
+            if (ins.a >= d->num_textures) return fail(PYR_ERR_INVALID_ARGUMENT, "texture id out of range");
+            if (d->textures[ins.a].format != (ins.op == PYR_OP_COLOR_TEXTURE ? PYR_TEXTURE_COLOR : PYR_TEXTURE_MONO))
+                return fail(PYR_ERR_INVALID_ARGUMENT, "texture format does not match the opcode");
+        }
+    }
+    for (uint32_t i = 0; i < d->num_textures; ++i) {
+        const PyrTexture& t = d->textures[i];
+        uint64_t floats = (uint64_t)t.width * t.height * (t.format == PYR_TEXTURE_COLOR ? 4u : 1u);
+        if (t.width == 0 || t.height == 0 || t.format > PYR_TEXTURE_MONO || t.offset + floats > d->num_texture_floats)
+            return fail(PYR_ERR_INVALID_ARGUMENT, "texture data out of range");
+    }
     for (uint32_t i = 0; i < d->num_materials; ++i) {
         const PyrMaterial& m = d->materials[i];
-        if (m.normal_map_program >= 0) return fail(PYR_ERR_UNSUPPORTED, "normal maps are out of scope");
+        if (m.normal_map_program >= 0 && (uint32_t)m.normal_map_program >= d->num_programs)
+            return fail(PYR_ERR_INVALID_ARGUMENT, "normal map program out of range");
         if (m.num_components == 0) return fail(PYR_ERR_INVALID_ARGUMENT, "material without components");
         if (m.first_component + m.num_components > d->num_components || m.first_emissive + m.num_emissive > d->num_components)
             return fail(PYR_ERR_INVALID_ARGUMENT, "material component range out of bounds");
@@ -1722,6 +1882,13 @@ int oracle_scene_create(const PyrSceneDesc* d, OracleScene** out) {
         t.edge2 = t.p3 - t.p1;
         t.material = d->tri_material[i];
         if (t.material >= d->num_materials) return fail(PYR_ERR_INVALID_ARGUMENT, "triangle material out of range");
+        t.f1 = t.f2 = t.f3 = Quat{1.0f, 0.0f, 0.0f, 0.0f};
+        if (d->tri_frames) {
+            const float* f = d->tri_frames + 12 * (size_t)i;
+            t.f1 = Quat{f[0], f[1], f[2], f[3]};
+            t.f2 = Quat{f[4], f[5], f[6], f[7]};
+            t.f3 = Quat{f[8], f[9], f[10], f[11]};
+        }
         s->triangles.push_back(t);
     }
     for (uint32_t i = 0; i < d->num_spheres; ++i) {
@@ -1744,6 +1911,14 @@ int oracle_scene_create(const PyrSceneDesc* d, OracleScene** out) {
         pl.tex_scale[1] = p[7];
         pl.material = d->plane_material[i];
         if (pl.material >= d->num_materials) return fail(PYR_ERR_INVALID_ARGUMENT, "plane material out of range");
+        if (d->plane_frames) {
+            const float* f = d->plane_frames + 4 * (size_t)i;
+            pl.frame = Quat{f[0], f[1], f[2], f[3]};
+        } else { // world.rs:88-100: basis(normal) -> Matrix3::from_cols(binormal, tangent, normal).into()
+            V3 z = normalize(ortho(pl.normal));
+            V3 y = normalize(cross(z, pl.normal));
+            pl.frame = quat_from_cols(y, z, pl.normal);
+        }
         s->planes.push_back(pl);
     }
     s->lamps.assign(d->lamps, d->lamps + d->num_lamps);
@@ -1757,6 +1932,13 @@ int oracle_scene_create(const PyrSceneDesc* d, OracleScene** out) {
     s->rgb_basis_min = d->rgb_basis_min;
     s->rgb_basis_max = d->rgb_basis_max;
     s->sky_program = d->sky_program;
+    if (d->num_textures) {
+        s->texture_data.assign(d->texture_data, d->texture_data + d->num_texture_floats);
+        for (uint32_t i = 0; i < d->num_textures; ++i) {
+            const PyrTexture& t = d->textures[i];
+            s->textures.push_back(Texture{t.width, t.height, t.format == PYR_TEXTURE_COLOR ? 4u : 1u, s->texture_data.data() + t.offset});
+        }
+    }
     build_bvh(*s);
     *out = s.release();
     return PYR_OK;
@@ -2010,6 +2192,37 @@ float oracle_run_program(OracleScene* scene, uint32_t program, float wavelength,
     float v = exe.run(program, in);
     if (wavelength_used) *wavelength_used = in.wavelength_used ? 1 : 0;
     return v;
+}
+
+void oracle_texture_get(uint32_t channels, uint32_t width, uint32_t height, const float* texels, float x, float y, float* out) {
+    Texture t{width, height, channels, texels};
+    texture_get_color(t, x, y, out);
+}
+void oracle_quat_from_cols(const float c0[3], const float c1[3], const float c2[3], float out[4]) {
+    Quat q = quat_from_cols(lv(c0), lv(c1), lv(c2));
+    out[0] = q.s, out[1] = q.x, out[2] = q.y, out[3] = q.z;
+}
+void oracle_quat_rotate(const float q[4], const float v[3], float out[3]) { sv(quat_rotate(Quat{q[0], q[1], q[2], q[3]}, lv(v)), out); }
+int oracle_surface_data(OracleScene* scene, const float ray6[6], float wavelength, float normal[3], float texture[2], float frame[4],
+                        float shading_normal[3]) {
+    Ray ray{v3(ray6[0], ray6[1], ray6[2]), v3(ray6[3], ray6[4], ray6[5])};
+    Intersection hit;
+    Counters c;
+    if (!world_intersect(*scene, ray, hit, c)) return 0;
+    SurfaceData sd = surface_data(*scene, hit);
+    sv(sd.normal, normal);
+    texture[0] = sd.texture[0], texture[1] = sd.texture[1];
+    frame[0] = sd.from_space.s, frame[1] = sd.from_space.x, frame[2] = sd.from_space.y, frame[3] = sd.from_space.z;
+    V3 n = sd.normal;
+    const PyrMaterial& material = scene->materials[shape_material(*scene, hit.shape)];
+    if (material.normal_map_program >= 0) {
+        Exe exe(scene);
+        ProgramInput in{wavelength, sd.normal, ray.direction, {sd.texture[0], sd.texture[1]}};
+        V4 m = exe.run_vector((uint32_t)material.normal_map_program, in);
+        n = normalize(quat_rotate(sd.from_space, v3(m.x, m.y, m.z)));
+    }
+    sv(n, shading_normal);
+    return 1;
 }
 
 // ---- film development: main.rs:315-327 (final pass), spectrum_to_xyz :352-369, spectrum_to_tristimulus :371-418,

@@ -95,6 +95,16 @@ uint32_t oracle_tile_order(uint32_t width, uint32_t height, uint32_t tile_size, 
 float oracle_run_program(OracleScene* scene, uint32_t program, float wavelength, const float normal[3],
                          const float incident[3], const float texture[2], int* wavelength_used);
 
+/* texture.rs:87-150 + :297-334: bicubic lookup with wrap-around in a [height][width][channels] texture ("next" row f4). */
+void oracle_texture_get(uint32_t channels, uint32_t width, uint32_t height, const float* texels, float x, float y, float* out);
+/* [3P] cgmath: Quaternion::from(Matrix3::from_cols(c0, c1, c2)) as (s, x, y, z); Quaternion * Vector3. */
+void oracle_quat_from_cols(const float c0[3], const float c1[3], const float c2[3], float out[4]);
+void oracle_quat_rotate(const float q[4], const float v[3], float out[3]);
+/* SurfacePoint::get_surface_data (shapes/mod.rs:484-494) + Material::apply_normal_map (materials/mod.rs:68-80) at the first
+ * hit of a ray; returns 0 on a miss. */
+int oracle_surface_data(OracleScene* scene, const float ray6[6], float wavelength, float normal[3], float texture[2], float frame[4],
+                        float shading_normal[3]);
+
 /* main.rs:315-327 + :352-418 + film.rs:282-337: develop a whole film into 8-bit sRGB ("next" row f1). */
 int oracle_film_develop(const PyrFilmDesc* film, const PyrGrain* grains, const PyrDevelopParams* params, uint8_t* rgb_out);
 

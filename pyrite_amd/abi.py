@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes and that every declared symbol is exported."""
 import ctypes as C
 
-PYR_ABI_VERSION = 1
+PYR_ABI_VERSION = 2
 
 PYR_OK = 0
 PYR_ERR_INVALID_ARGUMENT = -1
@@ -133,6 +133,12 @@ class PyrLamp(C.Structure):
     ]
 
 
+class PyrTexture(C.Structure):
+    _fields_ = [("format", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("reserved", C.c_uint32), ("offset", C.c_uint64)]
+
+
+TEXTURE_COLOR, TEXTURE_MONO = 0, 1
+
 _fp = C.POINTER(C.c_float)
 _up = C.POINTER(C.c_uint32)
 
@@ -170,6 +176,12 @@ class PyrSceneDesc(C.Structure):
         ("rgb_basis_min", C.c_float),
         ("rgb_basis_max", C.c_float),
         ("sky_program", C.c_uint32),
+        ("num_textures", C.c_uint32),
+        ("textures", C.POINTER(PyrTexture)),
+        ("num_texture_floats", C.c_uint64),
+        ("texture_data", _fp),
+        ("tri_frames", _fp),
+        ("plane_frames", _fp),
     ]
 
 

@@ -144,6 +144,66 @@ def _transform_vector(m, v):
     )
 
 
+# [3P] cgmath 0.17: Quaternion::from(Matrix3::from_cols(c0, c1, c2)) as (s, x, y, z), Quaternion * Vector3 -- the same
+# formulas as oracle.cpp's quat_from_cols / quat_rotate, in f32.
+def _quat_from_cols(c0, c1, c2):
+    m00, m01, m02 = f32(c0[0]), f32(c0[1]), f32(c0[2])
+    m10, m11, m12 = f32(c1[0]), f32(c1[1]), f32(c1[2])
+    m20, m21, m22 = f32(c2[0]), f32(c2[1]), f32(c2[2])
+    half, one = f32(0.5), f32(1.0)
+    with np.errstate(all="ignore"):
+        trace = m00 + m11 + m22
+        if trace >= 0:
+            s = np.sqrt(one + trace, dtype=f32)
+            w = half * s
+            s = half / s
+            q = [w, (m12 - m21) * s, (m20 - m02) * s, (m01 - m10) * s]
+        elif m00 > m11 and m00 > m22:
+            s = np.sqrt((m00 - m11 - m22) + one, dtype=f32)
+            x = half * s
+            s = half / s
+            q = [(m12 - m21) * s, x, (m10 + m01) * s, (m02 + m20) * s]
+        elif m11 > m22:
+            s = np.sqrt((m11 - m00 - m22) + one, dtype=f32)
+            y = half * s
+            s = half / s
+            q = [(m20 - m02) * s, (m10 + m01) * s, y, (m21 + m12) * s]
+        else:
+            s = np.sqrt((m22 - m00 - m11) + one, dtype=f32)
+            z = half * s
+            s = half / s
+            q = [(m01 - m10) * s, (m02 + m20) * s, (m21 + m12) * s, z]
+    return np.array(q, dtype=f32)
+
+
+def _quat_rotate(q, vec):
+    v = q[1:4]
+    with np.errstate(all="ignore"):
+        tmp = _cross(v, vec) + vec * q[0]
+        return (_cross(v, tmp) * f32(2.0) + vec).astype(f32)
+
+
+def _ortho(v):  # math.rs:98-114
+    eps = f32(1.0e-4)
+    if abs(v[0]) < eps:
+        unit = np.array([1, 0, 0], dtype=f32)
+    elif abs(v[1]) < eps:
+        unit = np.array([0, 1, 0], dtype=f32)
+    elif abs(v[2]) < eps:
+        unit = np.array([0, 0, 1], dtype=f32)
+    else:
+        unit = np.array([-v[1], v[0], 0], dtype=f32)
+    return _cross(v, unit)
+
+
+def _normal_transform(xform, vector, frame):  # Normal::transform, shapes/mod.rs:572-583
+    with np.errstate(all="ignore"):
+        n = _normalize(_transform_vector(xform, vector))
+        x = _normalize(_transform_vector(xform, _quat_rotate(frame, np.array([1, 0, 0], dtype=f32))))
+        y = _normalize(_transform_vector(xform, _quat_rotate(frame, np.array([0, 1, 0], dtype=f32))))
+    return n, _quat_from_cols(x, y, n)
+
+
 # ------------------------------------------------------------------------------------------------
 # expression helpers used by material flattening (expressions.rs:20-63)
 # ------------------------------------------------------------------------------------------------
@@ -182,6 +242,9 @@ class FlatScene:
         self.planes, self.plane_material = [], []
         self.lamps, self.materials, self.components, self.programs, self.instrs = [], [], [], [], []
         self.spectra, self.spectrum_data = [], []
+        self.tri_frames, self.plane_frames = [], []
+        self.textures, self._texture_ids = [], {}  # (format, texels) in id order; (path | id(array), linear, mono) -> id
+        self.uses_normal_maps = False
         self._spectrum_ids = {}
         self.uses_rgb_basis = False
         self.sky_program = 0
@@ -217,6 +280,31 @@ class FlatScene:
         self._keep_alive = getattr(self, "_keep_alive", [])
         self._keep_alive.append(e)  # ids stay unique while the expression object lives
         return sid
+
+    # ---- textures (TextureLoader::load_color / load_mono, project/textures.rs:56-118: one id per file and kind) ----
+    def texture_id(self, e, base_dir=None):
+        source, linear, mono = e.path, bool(e.get("linear")), e.type == "mono_texture"
+        if isinstance(source, (str, os.PathLike)):
+            path = os.fspath(source)
+            if not os.path.isabs(path):
+                path = os.path.join(base_dir or getattr(self, "base_dir", "."), path)
+            key = (os.path.normpath(path), linear, mono)
+        else:
+            key = (id(source), linear, mono)
+        if key in self._texture_ids:
+            return self._texture_ids[key]
+        from . import images
+
+        try:
+            texels = images.load_texture(key[0], linear, mono) if isinstance(key[0], str) else images.linearise(source, linear, mono)
+        except (OSError, ValueError) as error:  # textures.rs:78-83 / :102-107
+            raise ProjectError("could not load %s as %s texture: %s" % (key[0], "mono" if mono else "color", error))
+        tid = len(self.textures)
+        self.textures.append((abi.TEXTURE_MONO if mono else abi.TEXTURE_COLOR, texels))
+        self._texture_ids[key] = tid
+        self._keep_alive = getattr(self, "_keep_alive", [])
+        self._keep_alive.append(source)
+        return tid
 
     # ---- ProgramCompiler::compile (program/compiler.rs:48-586) ----
     def compile(self, expression, allow_wavelength=True, output="number"):
@@ -379,8 +467,12 @@ class FlatScene:
                     out = next_reg("n")
                     emit(op=abi.OP_SPECTRUM, x=wl, a=self.spectrum_id(e), output=out, deps=deps)
                     done(e, "n", out, deps)
-                elif t in ("color_texture", "mono_texture"):
-                    raise ProjectError("texture expressions are out of scope for the GPU path (SURVEY.md section 8)")
+                elif t in ("color_texture", "mono_texture"):  # compiler.rs:282-323
+                    ti, td = VEC_INPUT["texture"]
+                    kind = "c" if t == "color_texture" else "n"
+                    out = next_reg(kind)
+                    emit(op=abi.OP_COLOR_TEXTURE if kind == "c" else abi.OP_MONO_TEXTURE, a=self.texture_id(e), b=ti, output=out, deps=td)
+                    done(e, kind, out, td)
                 elif t == "mix":
                     amount, ad = try_get_number_value(e.amount)
                     lhs = try_get_register(e.lhs)
@@ -444,8 +536,10 @@ class FlatScene:
     def add_material(self, mat):
         surface = mat["surface"] if isinstance(mat, dict) else mat.surface
         normal_map = mat.get("normal_map") if isinstance(mat, dict) else mat.get("normal_map")
-        if normal_map is not None:
-            raise ProjectError("normal maps are out of scope for the GPU path (SURVEY.md section 8)")
+        normal_map_program = -1
+        if normal_map is not None:  # materials/mod.rs:41-44: a Vector program over NormalInput (no wavelength)
+            normal_map_program = self.compile(normal_map, allow_wavelength=False, output="vector")
+            self.uses_normal_maps = True
         stack = [(surface, None)]
         components, emissive = [], []
         while stack:
@@ -486,11 +580,12 @@ class FlatScene:
         self.components.extend(components)
         first_emissive = len(self.components)
         self.components.extend(emissive)
-        self.materials.append((first_component, len(components), first_emissive, len(emissive), -1))
+        self.materials.append((first_component, len(components), first_emissive, len(emissive), normal_map_program))
         return len(self.materials) - 1, len(emissive) > 0
 
     # ---- World::from_project (world.rs:39-271) ----
     def add_world(self, world, base_dir="."):
+        self.base_dir = base_dir  # texture paths are relative to the project directory (project/textures.rs:58-67)
         sky = world.get("sky") if isinstance(world, dict) else None
         self.sky_program = self.compile(sky if sky is not None else 0.0)
         objects = world["objects"] if isinstance(world, dict) else world.objects
@@ -512,6 +607,9 @@ class FlatScene:
                 origin = eval_vector(obj.origin)[:3]
                 scale = eval_vector(obj.texture_scale)[:2] if obj.texture_scale is not None else np.array([1, 1], dtype=f32)
                 self.planes.append([*origin, *normal, *scale])
+                z = _normalize(_ortho(normal))  # math::utils::basis, math.rs:119-123
+                y = _normalize(_cross(z, normal))
+                self.plane_frames.append(_quat_from_cols(y, z, normal))  # world.rs:95-99
                 self.plane_material.append(m)
             elif t == "mesh":
                 self._add_mesh(i, obj, base_dir)
@@ -556,15 +654,26 @@ class FlatScene:
             flat = _normalize(_cross(v[1] - v[0], v[2] - v[0]))
             n = [flat, flat, flat]
         uv = [T[ix[1]].astype(f32) if ix[1] is not None else np.zeros(2, dtype=f32) for ix in poly]
+        # tangent space from the uv deltas, world.rs:337-346 (before scale / transform)
+        with np.errstate(all="ignore"):
+            dp1, dp2 = v[1] - v[0], v[2] - v[0]
+            dt1, dt2 = uv[1] - uv[0], uv[2] - uv[0]
+            r = f32(1.0) / (dt1[0] * dt2[1] - dt1[1] * dt2[0])
+            tangent = (dp1 * dt2[1] - dp2 * dt1[1]) * r
+            bitangent = (dp2 * dt1[0] - dp1 * dt2[0]) * r
+            frames = [_quat_from_cols(tangent, bitangent, x) for x in n]
         v = [(p * scale).astype(f32) for p in v]  # Shape::scale, shapes/mod.rs:290-320
-        n = [_normalize(_transform_vector(xform, x)) for x in n]  # Normal::transform, shapes/mod.rs:572-583
+        transformed = [_normal_transform(xform, x, q) for x, q in zip(n, frames)]  # Normal::transform, shapes/mod.rs:572-583
+        n = [t[0] for t in transformed]
+        frames = [t[1] for t in transformed]
         v = [_transform_point(xform, p) for p in v]  # Shape::transform, shapes/mod.rs:322-344
-        self.add_triangle(v, n, uv, material)
+        self.add_triangle(v, n, uv, material, frames)
 
-    def add_triangle(self, positions, normals, uvs, material):
+    def add_triangle(self, positions, normals, uvs, material, frames=None):
         self.tri_positions.append(np.asarray(positions, dtype=f32).reshape(9))
         self.tri_normals.append(np.asarray(normals, dtype=f32).reshape(9))
         self.tri_uvs.append(np.asarray(uvs, dtype=f32).reshape(6))
+        self.tri_frames.append(np.asarray(frames, dtype=f32).reshape(12) if frames is not None else np.tile(np.array([1, 0, 0, 0], dtype=f32), 3))
         self.tri_material.append(material)
 
     def add_triangles(self, positions, normals, material, emissive=False):
@@ -575,6 +684,7 @@ class FlatScene:
         self.tri_positions.append(positions)
         self.tri_normals.append(normals)
         self.tri_uvs.append(np.zeros((len(positions), 6), dtype=f32))
+        self.tri_frames.append(np.tile(np.array([1, 0, 0, 0], dtype=f32), (len(positions), 3)))
         self.tri_material.extend([material] * len(positions))
         if emissive:
             for k in range(len(positions)):
@@ -666,6 +776,21 @@ class FlatScene:
             d.rgb_basis = basis.ctypes.data_as(C.POINTER(C.c_float))
             d.rgb_basis_count, d.rgb_basis_min, d.rgb_basis_max = len(basis), float(t["rgb_min"]), float(t["rgb_max"])
         d.sky_program = self.sky_program
+        if self.uses_normal_maps and n_tri:
+            d.tri_frames, _ = farr("tf", self.tri_frames, 12)
+        if n_pl and len(self.plane_frames) == n_pl:
+            d.plane_frames, _ = farr("pf", self.plane_frames, 4)
+        if self.textures:
+            records = (abi.PyrTexture * len(self.textures))()
+            offset, blobs = 0, []
+            for k, (fmt, texels) in enumerate(self.textures):
+                records[k] = abi.PyrTexture(fmt, texels.shape[1], texels.shape[0], 0, offset)
+                blobs.append(np.ascontiguousarray(texels, dtype=f32).reshape(-1))
+                offset += blobs[-1].size
+            data = np.ascontiguousarray(np.concatenate(blobs))
+            keep["tex"], keep["texrec"] = data, records
+            d.textures, d.num_textures = records, len(self.textures)
+            d.texture_data, d.num_texture_floats = data.ctypes.data_as(C.POINTER(C.c_float)), data.size
         keep.update(lamps=lamps, mats=mats, comps=comps, progs=progs, instrs=instrs, spectra=spectra)
         self._keep = keep  # the descriptor borrows these buffers
         return d

@@ -63,7 +63,11 @@ int validate(const PyrSceneDesc* d) {
     if (d->num_triangles >= (1u << 28) || d->num_spheres >= (1u << 28)) return fail(PYR_ERR_INVALID_ARGUMENT, "too many primitives");
     for (uint32_t i = 0; i < d->num_instrs; ++i) {
         const PyrInstr& ins = d->instrs[i];
-        if (ins.op == PYR_OP_COLOR_TEXTURE || ins.op == PYR_OP_MONO_TEXTURE) return fail(PYR_ERR_UNSUPPORTED, "texture opcodes are out of scope");
+        if (ins.op == PYR_OP_COLOR_TEXTURE || ins.op == PYR_OP_MONO_TEXTURE) {
+            if (ins.a >= d->num_textures || !d->textures) return fail(PYR_ERR_INVALID_ARGUMENT, "texture id out of range");
+            if (d->textures[ins.a].format != (ins.op == PYR_OP_COLOR_TEXTURE ? PYR_TEXTURE_COLOR : PYR_TEXTURE_MONO))
+                return fail(PYR_ERR_INVALID_ARGUMENT, "texture format does not match the opcode");
+        }
         if (ins.op > PYR_OP_CLAMP) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown opcode");
         if (ins.op == PYR_OP_SPECTRUM && ins.a >= d->num_spectra) return fail(PYR_ERR_INVALID_ARGUMENT, "spectrum id out of range");
         if (ins.op == PYR_OP_RGB_SPECTRUM && !d->rgb_basis) return fail(PYR_ERR_INVALID_ARGUMENT, "RgbSpectrumValue needs rgb_basis");
@@ -72,6 +76,12 @@ int validate(const PyrSceneDesc* d) {
         const PyrSpectrum& s = d->spectra[i];
         uint64_t floats = s.format == PYR_SPECTRUM_CURVE ? 2ull * s.count : s.count;
         if (s.offset + floats > d->num_spectrum_floats) return fail(PYR_ERR_INVALID_ARGUMENT, "spectrum data out of range");
+    }
+    for (uint32_t i = 0; i < d->num_textures; ++i) {
+        const PyrTexture& t = d->textures[i];
+        uint64_t floats = (uint64_t)t.width * t.height * (t.format == PYR_TEXTURE_COLOR ? 4u : 1u);
+        if (t.width == 0 || t.height == 0 || t.format > PYR_TEXTURE_MONO || !d->texture_data || t.offset + floats > d->num_texture_floats)
+            return fail(PYR_ERR_INVALID_ARGUMENT, "texture data out of range");
     }
     for (uint32_t i = 0; i < d->num_programs; ++i) {
         const PyrProgram& p = d->programs[i];
@@ -83,7 +93,8 @@ int validate(const PyrSceneDesc* d) {
     }
     for (uint32_t i = 0; i < d->num_materials; ++i) {
         const PyrMaterial& m = d->materials[i];
-        if (m.normal_map_program >= 0) return fail(PYR_ERR_UNSUPPORTED, "normal maps are out of scope");
+        if (m.normal_map_program >= 0 && (uint32_t)m.normal_map_program >= d->num_programs)
+            return fail(PYR_ERR_INVALID_ARGUMENT, "normal map program out of range");
         if (m.num_components == 0) return fail(PYR_ERR_INVALID_ARGUMENT, "material without components");
         if ((uint64_t)m.first_component + m.num_components > d->num_components || (uint64_t)m.first_emissive + m.num_emissive > d->num_components)
             return fail(PYR_ERR_INVALID_ARGUMENT, "material component range out of bounds");
@@ -180,7 +191,7 @@ struct PyrScene {
     DevScene dev{};
     PyrBvhInfo info{};
     DeviceBuffer nodes, prims, tri_shade, spheres, sphere_material, planes, plane_material, lamps, materials, components, programs, instrs, spectra,
-        spectrum_data, rgb_basis, counters;
+        spectrum_data, rgb_basis, counters, tri_tex, sphere_tex_scale, plane_frames, textures, texture_data;
     PyrCounters last_counters{};
     bool have_counters = false;
     uint32_t* tail_count = nullptr; // device, kFeedBytes: the work-feed cursors of the intersect kernel
@@ -195,6 +206,53 @@ struct PyrScene {
 };
 
 namespace {
+
+// world.rs:88-100 for a caller that did not pass plane_frames: basis(normal) (math.rs:98-123) and
+// Matrix3::from_cols(binormal, tangent, normal).into() -- the f32 operations of oracle.cpp's ortho / normalize / cross /
+// quat_from_cols in the same order (this file is built with -ffp-contract=off).
+void plane_frame_from_normal(const float n[3], float q[4]) {
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    auto normalize = [](float v[3]) {
+        float m = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        float k = 1.0f / m;
+        v[0] *= k, v[1] *= k, v[2] *= k;
+    };
+    float unit[3] = {-n[1], n[0], 0.0f};
+    if (std::fabs(n[0]) < 1.0e-4f)
+        unit[0] = 1.0f, unit[1] = 0.0f, unit[2] = 0.0f;
+    else if (std::fabs(n[1]) < 1.0e-4f)
+        unit[0] = 0.0f, unit[1] = 1.0f, unit[2] = 0.0f;
+    else if (std::fabs(n[2]) < 1.0e-4f)
+        unit[0] = 0.0f, unit[1] = 0.0f, unit[2] = 1.0f;
+    float z[3], y[3];
+    cross(n, unit, z);
+    normalize(z);
+    cross(z, n, y);
+    normalize(y);
+    const float m00 = y[0], m01 = y[1], m02 = y[2], m10 = z[0], m11 = z[1], m12 = z[2], m20 = n[0], m21 = n[1], m22 = n[2];
+    const float trace = m00 + m11 + m22;
+    if (trace >= 0.0f) {
+        float s = std::sqrt(1.0f + trace), w = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = w, q[1] = (m12 - m21) * s, q[2] = (m20 - m02) * s, q[3] = (m01 - m10) * s;
+    } else if (m00 > m11 && m00 > m22) {
+        float s = std::sqrt((m00 - m11 - m22) + 1.0f), x = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (m12 - m21) * s, q[1] = x, q[2] = (m10 + m01) * s, q[3] = (m02 + m20) * s;
+    } else if (m11 > m22) {
+        float s = std::sqrt((m11 - m00 - m22) + 1.0f), yy = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (m20 - m02) * s, q[1] = (m10 + m01) * s, q[2] = yy, q[3] = (m21 + m12) * s;
+    } else {
+        float s = std::sqrt((m22 - m00 - m11) + 1.0f), zz = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (m01 - m10) * s, q[1] = (m02 + m20) * s, q[2] = (m21 + m12) * s, q[3] = zz;
+    }
+}
 
 int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     // ---- primitives + BVH
@@ -271,6 +329,8 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             o.width = p[3];
             o.area = p[3] * p[3] * 4.0f * 3.14159265358979323846f; // Shape::surface_area, shapes/mod.rs:275
             o.material = d->sphere_material[l.shape_index];
+            o.t1[0] = d->sphere_tex_scale ? d->sphere_tex_scale[2 * (size_t)l.shape_index] : 1.0f;
+            o.t1[1] = d->sphere_tex_scale ? d->sphere_tex_scale[2 * (size_t)l.shape_index + 1] : 1.0f;
         } else if (l.kind == PYR_LAMP_SHAPE) {
             const float* p = d->tri_positions + 9 * (size_t)l.shape_index;
             const float* n = d->tri_normals + 9 * (size_t)l.shape_index;
@@ -292,12 +352,63 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             volatile float s2 = s1 + zz;
             o.area = 0.5f * std::sqrt(s2);
             o.material = d->tri_material[l.shape_index];
+            if (d->tri_uvs) {
+                const float* uv = d->tri_uvs + 6 * (size_t)l.shape_index;
+                o.t1[0] = uv[0], o.t1[1] = uv[1], o.t2[0] = uv[2], o.t2[1] = uv[3], o.t3[0] = uv[4], o.t3[1] = uv[5];
+            }
         }
     }
     std::vector<DevProgram> programs(d->num_programs);
     for (uint32_t i = 0; i < d->num_programs; ++i) programs[i] = pack_program(d, d->programs[i]);
 
+    bool needs_interpreter = false, uses_textures = false;
+    for (const DevProgram& pr : programs)
+        if (pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast == FAST_NONE) needs_interpreter = true;
+    for (uint32_t i = 0; i < d->num_instrs; ++i)
+        if (d->instrs[i].op == PYR_OP_COLOR_TEXTURE || d->instrs[i].op == PYR_OP_MONO_TEXTURE) uses_textures = true;
+    for (uint32_t i = 0; i < d->num_materials; ++i)
+        if (d->materials[i].normal_map_program >= 0) uses_textures = needs_interpreter = true;
+
+    // texture space: only the interpreter builds of the kernels read it
+    std::vector<DevTriTex> tri_tex;
+    std::vector<float> sphere_scale, plane_frames;
+    std::vector<DevTexture> textures(d->num_textures);
+    if (needs_interpreter) {
+        tri_tex.resize(d->num_triangles);
+        for (uint32_t i = 0; i < d->num_triangles; ++i) {
+            DevTriTex& o = tri_tex[i];
+            std::memset(&o, 0, sizeof(o));
+            if (d->tri_uvs) {
+                const float* uv = d->tri_uvs + 6 * (size_t)i;
+                for (int a = 0; a < 4; ++a) o.uv12[a] = uv[a];
+                o.uv3[0] = uv[4], o.uv3[1] = uv[5];
+            }
+            o.f1[0] = o.f2[0] = o.f3[0] = 1.0f; // identity
+            if (d->tri_frames) {
+                const float* f = d->tri_frames + 12 * (size_t)i;
+                for (int a = 0; a < 4; ++a) o.f1[a] = f[a], o.f2[a] = f[4 + a], o.f3[a] = f[8 + a];
+            }
+        }
+        sphere_scale.assign(2 * (size_t)d->num_spheres, 1.0f);
+        if (d->sphere_tex_scale) sphere_scale.assign(d->sphere_tex_scale, d->sphere_tex_scale + 2 * (size_t)d->num_spheres);
+        plane_frames.resize(4 * (size_t)d->num_planes);
+        for (uint32_t i = 0; i < d->num_planes; ++i) {
+            if (d->plane_frames) {
+                for (int a = 0; a < 4; ++a) plane_frames[4 * (size_t)i + a] = d->plane_frames[4 * (size_t)i + a];
+            } else {
+                plane_frame_from_normal(d->planes + 8 * (size_t)i + 3, &plane_frames[4 * (size_t)i]);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < d->num_textures; ++i)
+        textures[i] = DevTexture{d->textures[i].format == PYR_TEXTURE_COLOR ? 4u : 1u, d->textures[i].width, d->textures[i].height, 0u, d->textures[i].offset};
+
     int rc;
+    if ((rc = s->tri_tex.upload(tri_tex.data(), tri_tex.size() * sizeof(DevTriTex)))) return rc;
+    if ((rc = s->sphere_tex_scale.upload(sphere_scale.data(), sphere_scale.size() * 4))) return rc;
+    if ((rc = s->plane_frames.upload(plane_frames.data(), plane_frames.size() * 4))) return rc;
+    if ((rc = s->textures.upload(textures.data(), textures.size() * sizeof(DevTexture)))) return rc;
+    if ((rc = s->texture_data.upload(d->texture_data, d->num_textures ? (size_t)d->num_texture_floats * 4 : 0))) return rc;
     if ((rc = s->nodes.upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64)))) return rc;
     if ((rc = s->prims.upload(prims.data(), prims.size() * sizeof(DevPrim)))) return rc;
     if ((rc = s->tri_shade.upload(shade.data(), shade.size() * sizeof(DevTriShade)))) return rc;
@@ -349,9 +460,13 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         const bool big_scene = (size_t)bvh.nodes.size() * 64 + prims.size() * 48 > 8 * 1024;
         v.lds_table_floats = (floats <= 3072 && big_scene) ? floats : 0;
     }
-    v.needs_interpreter = 0;
-    for (const DevProgram& pr : programs)
-        if (pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast == FAST_NONE) v.needs_interpreter = 1;
+    v.needs_interpreter = needs_interpreter ? 1u : 0u;
+    v.uses_textures = uses_textures ? 1u : 0u;
+    v.tri_tex = (const float*)s->tri_tex.ptr;
+    v.sphere_tex_scale = (const float*)s->sphere_tex_scale.ptr;
+    v.plane_frames = (const float*)s->plane_frames.ptr;
+    v.textures = (const DevTexture*)s->textures.ptr;
+    v.texture_data = (const float*)s->texture_data.ptr;
 
     s->info.num_nodes = (uint32_t)bvh.nodes.size();
     s->info.num_leaves = bvh.num_leaves;
@@ -457,6 +572,8 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 2;
     else
         L.scheduler = scene_is_lds_resident(scene->dev) ? 0u : 1u;
+    // texture coordinates and normal maps live in the resumable integrator (Walker); the synchronous walk has no texture path
+    if (L.scheduler == 0 && scene->dev.uses_textures) L.scheduler = 1;
     if (L.scheduler == 2) {
         WfPool pool{};
         int rc = wavefront_pool(scene, L, pool);

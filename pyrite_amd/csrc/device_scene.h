@@ -15,10 +15,22 @@ struct DevPrim {
 };
 
 // Shading record of a triangle, indexed by ORIGINAL triangle index, 48 bytes:
-//   (n1.xyz, material), (n2.xyz, 0), (n3.xyz, 0).  Texture coordinates are not uploaded: only texture opcodes read
-//   them and those are out of scope.
+//   (n1.xyz, material), (n2.xyz, 0), (n3.xyz, 0).
 struct DevTriShade {
     float n1[4], n2[4], n3[4];
+};
+
+// Texture-space record of a triangle (only uploaded for scenes that run the program interpreter), 80 bytes:
+//   uv = (t1.xy, t2.xy), (t3.xy, 0, 0); frames = Vertex.normal.from_space of v1, v2, v3 as (s, x, y, z).
+struct DevTriTex {
+    float uv12[4], uv3[4], f1[4], f2[4], f3[4];
+};
+
+struct DevTexture {
+    uint32_t channels; // 4 (LinSrgba) or 1 (LinLuma)
+    uint32_t width, height;
+    uint32_t reserved;
+    unsigned long long offset; // floats into DevScene::texture_data
 };
 
 // Lamp with everything Lamp::sample (lamp.rs:23-82) touches pre-gathered.
@@ -30,6 +42,7 @@ struct DevLamp {
     float n1[3], n2[3], n3[3]; // triangle lamp vertex normals
     float area;                // Shape::surface_area
     uint32_t material;
+    float t1[2], t2[2], t3[2]; // triangle lamp: vertex texture coordinates; sphere lamp: t1 = texture_scale
 };
 
 enum FastProgram : uint32_t {
@@ -75,6 +88,13 @@ struct DevScene {
     uint32_t num_nodes, num_prims;
     uint32_t num_spectra, num_spectrum_floats;
     uint32_t lds_table_floats; // > 0: the spectrum tables are staged into LDS (this many floats)
+    // texture space (interpreter builds only)
+    const float* tri_tex;          // DevTriTex[] by original triangle index, or nullptr
+    const float* sphere_tex_scale; // [n][2]
+    const float* plane_frames;     // [n][4] quaternion (s, x, y, z)
+    const DevTexture* textures;
+    const float* texture_data;
+    uint32_t uses_textures; // some program holds a texture opcode or some material a normal map
 };
 
 constexpr uint32_t kMaxStackDepth = 40; // >= kMaxBvhDepth (bvh.h): the deepest tree build_bvh produces

@@ -271,14 +271,61 @@ DEV float blackbody(float wavelength, float temperature) {
     return power_term / (exp32(1.4388e-2f / (wl * temperature)) - 1.0f);
 }
 
-struct VmInput { // RenderContext / ProbabilityInput
+struct VmInput { // RenderContext / ProbabilityInput / NormalInput
     float wavelength;
     f3 normal, incident;
+    float tx = 0.0f, ty = 0.0f; // texture coordinates
 };
+
+// Texture::get_color (texture.rs:87-150) + bicubic_interpolate / cubic_interpolate (:297-334): 4 x 4 texels around the
+// position with wrap-around, rows counted from the top of the image, one channel at a time (LinSrgba's operators are
+// component-wise). Same operation order as oracle.cpp's texture_get_color.
+DEV float cubic_interpolate(float v1, float v2, float v3, float v4, float pos) {
+    float a = (v4 - v3) - (v1 - v2);
+    float b = (v1 - v2) - a;
+    float c = v3 - v1;
+    float d = v2;
+    return d + (c + (b + a * pos) * pos) * pos;
+}
+DEV void texture_get(const DevScene& S, uint32_t id, float px, float py, float out[4]) {
+    const DevTexture t = S.textures[id];
+    const float* data = S.texture_data + t.offset;
+    const int w = (int)t.width, h = (int)t.height;
+    float x = px * (float)t.width - 0.5f;
+    float x_floor = floorf(x);
+    float y = (1.0f - py) * (float)t.height - 0.5f;
+    float y_floor = floorf(y);
+    // `as isize` saturates and maps NaN to 0; rem_euclid keeps the result in [0, n)
+    auto wrap = [](float f, int n) -> int {
+        long long i = (f != f) ? 0ll : (f >= 9.2233720368547758e18f ? 0x7fffffffffffffffll : (f <= -9.2233720368547758e18f ? (long long)0x8000000000000000ull : (long long)f));
+        long long r = i % (long long)n;
+        return (int)(r < 0 ? r + n : r);
+    };
+    int xs[4], ys[4];
+    xs[1] = wrap(x_floor, w);
+    xs[0] = xs[1] == 0 ? w - 1 : xs[1] - 1;
+    xs[2] = xs[1] == w - 1 ? 0 : xs[1] + 1;
+    xs[3] = xs[2] == w - 1 ? 0 : xs[2] + 1;
+    ys[1] = wrap(y_floor, h);
+    ys[0] = ys[1] == 0 ? h - 1 : ys[1] - 1;
+    ys[2] = ys[1] == h - 1 ? 0 : ys[1] + 1;
+    ys[3] = ys[2] == h - 1 ? 0 : ys[2] + 1;
+    const float fx = x - x_floor, fy = y - y_floor;
+    for (uint32_t ch = 0; ch < t.channels; ++ch) {
+        float rows[4];
+        for (int r = 0; r < 4; ++r) {
+            const float* row = data + (size_t)ys[r] * t.width * t.channels + ch;
+            rows[r] = cubic_interpolate(row[(size_t)xs[0] * t.channels], row[(size_t)xs[1] * t.channels], row[(size_t)xs[2] * t.channels],
+                                        row[(size_t)xs[3] * t.channels], fx);
+        }
+        out[ch] = cubic_interpolate(rows[0], rows[1], rows[2], rows[3], fy);
+    }
+}
 
 // The register interpreter (program/execution_context.rs:69-283). Programs are pure functions of their input, so the
 // reference's memoised re-run (execute only wavelength-dependent instructions) and a full run give the same value.
-__device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgram& p, const VmInput& in) {
+// `vector_out` (normal maps): receives the four components of a Vector program's output register.
+__device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgram& p, const VmInput& in, float* vector_out = nullptr) {
     float num[PYR_MAX_NUMBER_REGISTERS];
     float vec[PYR_MAX_VECTOR_REGISTERS][4];
     float rgb[PYR_MAX_RGB_REGISTERS][4];
@@ -288,7 +335,7 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
         return num[o.bits & (PYR_MAX_NUMBER_REGISTERS - 1)];
     };
     auto vinput = [&](uint32_t which, float out[4]) {
-        f3 v = which == PYR_INPUT_NORMAL ? in.normal : (which == PYR_INPUT_INCIDENT ? in.incident : mk(0, 0, 0));
+        f3 v = which == PYR_INPUT_NORMAL ? in.normal : (which == PYR_INPUT_INCIDENT ? in.incident : mk(in.tx, in.ty, 0.0f));
         out[0] = v.x;
         out[1] = v.y;
         out[2] = v.z;
@@ -320,6 +367,23 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
             break;
         }
         case PYR_OP_SPECTRUM: num[out & 15] = spectrum_get(S, ins.a, value(ins.x)); break;
+        case PYR_OP_COLOR_TEXTURE: { // execution_context.rs:114-126
+            float pos[4];
+            vinput(ins.b, pos);
+            float c[4];
+            texture_get(S, ins.a, pos[0], pos[1], c);
+            float* v = rgb[out & 3];
+            for (int j = 0; j < 4; ++j) v[j] = c[j];
+            break;
+        }
+        case PYR_OP_MONO_TEXTURE: { // :127-139
+            float pos[4];
+            vinput(ins.b, pos);
+            float c[4];
+            texture_get(S, ins.a, pos[0], pos[1], c);
+            num[out & 15] = c[0];
+            break;
+        }
         case PYR_OP_RGB_SPECTRUM: {
             float wl = value(ins.x);
             const float* c = rgb[ins.a & 3];
@@ -398,7 +462,13 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
         default: break;
         }
     }
-    if (p.output_kind == PYR_OUTPUT_NUMBER) return num[p.output_reg & 15];
+    if (p.output_kind == PYR_OUTPUT_NUMBER) {
+        const float n = num[p.output_reg & 15];
+        if (vector_out) vector_out[0] = vector_out[1] = vector_out[2] = vector_out[3] = n;
+        return n;
+    }
+    if (vector_out)
+        for (int j = 0; j < 4; ++j) vector_out[j] = vec[p.output_reg & 3][j];
     return vec[p.output_reg & 3][0];
 }
 
@@ -779,6 +849,124 @@ DEV void surface_at(const DevScene& S, const Hit& hit, f3 o, f3 d, f3& position,
     }
 }
 
+// ---- texture space (interpreter builds): Normal {vector, from_space} (shapes/mod.rs:531-584) ------------------------
+// [3P] cgmath 0.17 quaternion arithmetic, the same operation order as oracle.cpp's Quat helpers.
+struct Quat {
+    float s, x, y, z;
+};
+DEV Quat quat_scale(Quat q, float f) { return Quat{q.s * f, q.x * f, q.y * f, q.z * f}; }
+DEV Quat quat_add(Quat a, Quat b) { return Quat{a.s + b.s, a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV Quat quat_normalize(Quat q) {
+    float m = sqrtf(q.s * q.s + q.x * q.x + q.y * q.y + q.z * q.z);
+    return quat_scale(q, 1.0f / m);
+}
+DEV Quat quat_conjugate(Quat q) { return Quat{q.s, -q.x, -q.y, -q.z}; }
+DEV f3 quat_rotate(Quat q, f3 vec) {
+    f3 v = mk(q.x, q.y, q.z);
+    f3 tmp = cross(v, vec) + vec * q.s;
+    return cross(v, tmp) * 2.0f + vec;
+}
+DEV Quat quat_from_cols(f3 c0, f3 c1, f3 c2) {
+    const float m00 = c0.x, m01 = c0.y, m02 = c0.z, m10 = c1.x, m11 = c1.y, m12 = c1.z, m20 = c2.x, m21 = c2.y, m22 = c2.z;
+    float trace = m00 + m11 + m22;
+    if (trace >= 0.0f) {
+        float s = sqrtf(1.0f + trace);
+        float w = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{w, (m12 - m21) * s, (m20 - m02) * s, (m01 - m10) * s};
+    } else if (m00 > m11 && m00 > m22) {
+        float s = sqrtf((m00 - m11 - m22) + 1.0f);
+        float x = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{(m12 - m21) * s, x, (m10 + m01) * s, (m02 + m20) * s};
+    } else if (m11 > m22) {
+        float s = sqrtf((m11 - m00 - m22) + 1.0f);
+        float y = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{(m20 - m02) * s, (m10 + m01) * s, y, (m21 + m12) * s};
+    } else {
+        float s = sqrtf((m22 - m00 - m11) + 1.0f);
+        float z = 0.5f * s;
+        s = 0.5f / s;
+        return Quat{(m01 - m10) * s, (m02 + m20) * s, (m21 + m12) * s, z};
+    }
+}
+DEV float atan2_32(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+// Texture coordinates of a point on a sphere (get_sphere_surface_data, shapes/mod.rs:346-372).
+DEV void sphere_texture(f3 normal, float scale_x, float scale_y, float& latitude, float& longitude, float& tx, float& ty) {
+    latitude = acos32(normal.y);
+    longitude = atan2_32(normal.x, normal.z);
+    tx = (longitude * (1.0f / PI_F) * 0.5f) / scale_x;
+    ty = (1.0f - (latitude * (1.0f / PI_F))) / scale_y;
+}
+
+// SurfacePoint::get_surface_data with texture coordinates (shapes/mod.rs:346-385, :454-469, :484-494) followed by
+// Material::apply_normal_map (materials/mod.rs:68-80, tracer.rs:227-232): the shading normal, the material, the texture
+// coordinates. The tangent frame is only built for materials that have a normal map.
+DEV void surface_textured(const DevScene& S, const Hit& hit, f3 o, f3 d, f3& position, f3& normal, uint32_t& material, float& tx, float& ty) {
+    const uint32_t kind = hit.shape >> 30, index = hit.shape & 0x3FFFFFFFu;
+    Quat frame{1.0f, 0.0f, 0.0f, 0.0f};
+    if (kind == PYR_SHAPE_TRIANGLE) {
+        const float4* sh = reinterpret_cast<const float4*>(S.tri_shade) + 3 * (size_t)index;
+        const float4 a = sh[0], b = sh[1], c = sh[2];
+        const float w = 1.0f - (hit.u + hit.v);
+        normal = normalize(mk(a.x, a.y, a.z) * w + mk(b.x, b.y, b.z) * hit.u + mk(c.x, c.y, c.z) * hit.v);
+        material = __float_as_uint(a.w);
+        position = o + d * hit.t;
+        const float4* tt = reinterpret_cast<const float4*>(S.tri_tex) + 5 * (size_t)index;
+        const float4 uv12 = tt[0], uv3 = tt[1];
+        tx = uv12.x * w + uv12.z * hit.u + uv3.x * hit.v;
+        ty = uv12.y * w + uv12.w * hit.u + uv3.y * hit.v;
+        if (S.materials[material].normal_map_program >= 0) {
+            const float4 f1 = tt[2], f2 = tt[3], f3_ = tt[4];
+            frame = quat_normalize(quat_add(quat_add(quat_scale(Quat{f1.x, f1.y, f1.z, f1.w}, w), quat_scale(Quat{f2.x, f2.y, f2.z, f2.w}, hit.u)),
+                                            quat_scale(Quat{f3_.x, f3_.y, f3_.z, f3_.w}, hit.v)));
+        }
+    } else if (kind == PYR_SHAPE_SPHERE) {
+        const float4 sp = reinterpret_cast<const float4*>(S.spheres)[index];
+        float dist;
+        sphere_test(mk(sp.x, sp.y, sp.z), sp.w, o, d, dist, position);
+        normal = normalize(position - mk(sp.x, sp.y, sp.z));
+        material = S.sphere_material[index];
+        float latitude, longitude;
+        sphere_texture(normal, S.sphere_tex_scale[2 * index], S.sphere_tex_scale[2 * index + 1], latitude, longitude, tx, ty);
+        if (S.materials[material].normal_map_program >= 0) {
+            // Matrix3::from_angle_y(longitude) * Matrix3::from_angle_x(latitude - PI / 2) [3P], see oracle.cpp surface_data
+            const float sy = sin32(longitude), cy = cos32(longitude);
+            const float ax = latitude - PI_F * 0.5f;
+            const float sx = sin32(ax), cx = cos32(ax);
+            const f3 bc[3] = {mk(1.0f, 0.0f, 0.0f), mk(0.0f, cx, sx), mk(0.0f, -sx, cx)};
+            f3 col[3];
+            for (int j = 0; j < 3; ++j)
+                col[j] = mk(cy * bc[j].x + 0.0f * bc[j].y + sy * bc[j].z, 0.0f * bc[j].x + 1.0f * bc[j].y + 0.0f * bc[j].z,
+                            -sy * bc[j].x + 0.0f * bc[j].y + cy * bc[j].z);
+            frame = quat_from_cols(col[0], col[1], col[2]);
+        }
+    } else {
+        const float* pl = S.planes + 8 * index;
+        float dist;
+        plane_test(ld3(pl), ld3(pl + 3), o, d, dist, position);
+        normal = ld3(pl + 3);
+        material = S.plane_material[index];
+        const float* f = S.plane_frames + 4 * index;
+        frame = Quat{f[0], f[1], f[2], f[3]};
+        const f3 normal_space = quat_rotate(quat_conjugate(frame), position); // Normal::into_space
+        tx = normal_space.x / pl[6];
+        ty = normal_space.y / pl[7];
+    }
+    const int normal_map = S.materials[material].normal_map_program;
+    if (normal_map >= 0) {
+        const DevProgram prog = S.programs[normal_map];
+        float v[4] = {prog.constant, prog.constant, prog.constant, prog.constant};
+        if (prog.kind != PYR_PROGRAM_CONSTANT) {
+            const VmInput in{0.0f, normal, d, tx, ty};
+            run_interpreter(S, prog, in, v);
+        }
+        normal = normalize(quat_rotate(frame, mk(v[0], v[1], v[2])));
+    }
+}
+
 // materials/refractive.rs:47-91
 DEV void refract(float ior, float env_ior, f3 in_direction, f3 normal, Rng& rng, f3& out, float& prob) {
     f3 nl = dot(normal, in_direction) < 0.0f ? normal : -normal;
@@ -816,11 +1004,15 @@ struct LampSample { // lamp.rs:116-130
     f3 normal;
     uint32_t material, color;
     float weight;
+    float tx, ty; // Surface::Physical::texture (TEX builds only)
 };
 
 // Lamp::sample (lamp.rs:23-82) with Shape::sample_towards / sample_point / solid_angle_towards (shapes/mod.rs:166-271).
+// TEX: also the sampled point's texture coordinates (lamp.rs:64, :75).
+template <bool TEX = false>
 DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
     LampSample ls;
+    ls.tx = ls.ty = 0.0f;
     ls.physical = false;
     ls.material = 0;
     ls.color = lamp.color_program;
@@ -868,6 +1060,10 @@ DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
         }
         ls.physical = true;
         ls.material = lamp.material;
+        if constexpr (TEX) {
+            float latitude, longitude;
+            sphere_texture(ls.normal, lamp.t1[0], lamp.t1[1], latitude, longitude, ls.tx, ls.ty);
+        }
     } else {
         float u = rng_f32(rng);
         float v = rng_f32(rng);
@@ -888,6 +1084,10 @@ DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
         ls.weight = cos_in * lamp.area / ls.sq_distance;
         ls.physical = true;
         ls.material = lamp.material;
+        if constexpr (TEX) {
+            ls.tx = lamp.t1[0] * w + lamp.t2[0] * u + lamp.t3[0] * v;
+            ls.ty = lamp.t1[1] * w + lamp.t2[1] * u + lamp.t3[1] * v;
+        }
     }
     return ls;
 }
@@ -1486,6 +1686,7 @@ struct Walker {
     uint32_t ls_material = 0, ls_color = 0;
     f3 ls_normal = mk(0, 0, 0);
     float ls_scale = 0.0f;
+    float ls_tx = 0.0f, ls_ty = 0.0f; // its texture coordinates (interpreter builds)
     // what this visit changed, for schedulers that keep the state in memory between phases (dead code elsewhere)
     uint32_t touched = 0;
 
@@ -1573,14 +1774,18 @@ struct Walker {
         Hit hit{t.closest, t.shape, t.u, t.v};
         f3 position, normal;
         uint32_t material_id;
-        surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
+        float tx = 0.0f, ty = 0.0f;
+        if constexpr (INTERP)
+            surface_textured(S, hit, ray_o, ray_d, position, normal, material_id, tx, ty);
+        else
+            surface_at(S, hit, ray_o, ray_d, position, normal, material_id);
         const PyrMaterial material = S.materials[material_id];
         const uint32_t pick = rng_choose(p.rng, material.num_components);
         const PyrComponent comp = S.components[material.first_component + pick];
         float component_probability = comp.selection_compensation;
         bool normal_dispersed = false;
         if (comp.probability_program >= 0) {
-            VmInput pin{p.wl, normal, ray_d};
+            VmInput pin{p.wl, normal, ray_d, tx, ty};
             component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
             normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
         }
@@ -1588,7 +1793,7 @@ struct Walker {
             if (p.sample_light) {
                 p.use_additional = !normal_dispersed && p.use_additional;
                 const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
-                VmInput in{p.wl, normal, ray_d};
+                VmInput in{p.wl, normal, ray_d, tx, ty};
                 p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
                 if (p.use_additional)
                     for (uint32_t k = 0; k < n_add; ++k) {
@@ -1624,7 +1829,7 @@ struct Walker {
         p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
         {
             const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
-            VmInput in{p.wl, normal, ray_d};
+            VmInput in{p.wl, normal, ray_d, tx, ty};
             p.refl *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
             if (p.use_additional)
                 for (uint32_t k = 0; k < n_add; ++k) {
@@ -1678,7 +1883,7 @@ struct Walker {
                     const PyrComponent ec = S.components[lm.first_emissive + e_pick];
                     material_probability = ec.selection_compensation;
                     if (ec.probability_program >= 0) {
-                        VmInput pin{p.wl, ls_normal, t.d};
+                        VmInput pin{p.wl, ls_normal, t.d, ls_tx, ls_ty};
                         material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
                         l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
                     }
@@ -1688,7 +1893,7 @@ struct Walker {
                 const float l_probability = ls_scale * material_probability;
                 touched |= TOUCH_BRIGHT;
                 const Prepared q_prog = prepare_program<INTERP>(S, l_color);
-                VmInput in{p.wl, target_normal, t.d};
+                VmInput in{p.wl, target_normal, t.d, ls_physical ? ls_tx : 0.0f, ls_physical ? ls_ty : 0.0f};
                 p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
                 if (p.use_additional && !l_dispersed)
                     for (uint32_t k = 0; k < n_add; ++k) {
@@ -1699,7 +1904,7 @@ struct Walker {
         }
         const DevLamp& lamp = S.lamps[nee_lamp];
         while (nee_i < L.light_samples) {
-            const LampSample ls = lamp_sample(lamp, p.rng, b_position);
+            const LampSample ls = lamp_sample<INTERP>(lamp, p.rng, b_position);
             nee_i++;
             const float cos_out = fmaxf(dot(b_nff, ls.direction), 0.0f);
             if (!(cos_out > 0.0f)) continue;
@@ -1710,6 +1915,7 @@ struct Walker {
             ls_material = ls.material;
             ls_color = ls.color;
             ls_normal = ls.normal;
+            ls_tx = ls.tx, ls_ty = ls.ty;
             ls_pending = true;
             touched |= TOUCH_LIGHT;
             // a shadow ray decided by a plane alone comes straight back to this phase
@@ -1890,7 +2096,7 @@ DEV f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 // State groups (float4 each, [group][slot]):
 //   0 chunk | bounce, events, flags | nee_lamp | nee_i        6 closest, shape, u, v (planes' result in, hit out)
 //   1 rng                                                     7 b_position     8 b_normal     9 b_out     10 b_nff
-//   2 px, py, wl, bright                                      11 ls_normal
+//   2 px, py, wl, bright                                      11 ls_normal (+ ls_ty; ls_tx rides in 10.w)
 //   3 refl, nee_probability, ls_scale, ls_color
 //   4 ray origin, limit        5 ray direction, ls_material
 // A visit loads what its entry stage reads (a path coming back from an extension ray does not need the light-sample
@@ -1923,6 +2129,7 @@ DEV void wf_load(const WfPool& P, uint32_t slot, uint32_t word, bool planes, Wal
     if (w.stage == ST_NEE) {
         const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n], g10 = g[10 * n], g11 = g[11 * n];
         w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9), w.b_nff = xyz(g10), w.ls_normal = xyz(g11);
+        w.ls_tx = g10.w, w.ls_ty = g11.w;
         w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event)
     } else {
         const float4 g4 = g[4 * n];
@@ -1963,7 +2170,8 @@ DEV void wf_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUN
         g[9 * n] = mk4(w.b_out, 0.0f);
         g[10 * n] = mk4(w.b_nff, 0.0f);
     }
-    if (w.touched & TOUCH_LIGHT) g[11 * n] = mk4(w.ls_normal, 0.0f);
+    if (w.touched & TOUCH_LIGHT) g[11 * n] = mk4(w.ls_normal, w.ls_ty);
+    if (INTERP && (w.touched & TOUCH_LIGHT)) g[10 * n] = mk4(w.b_nff, w.ls_tx); // the light sample's texture coordinates ride in the spare lanes
     float* c = P.companions + slot;
     if (w.touched & TOUCH_NEW)
         for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(0 * n_comp + k) * n] = spec.wl(k);

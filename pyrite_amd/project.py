@@ -106,7 +106,7 @@ def rgb(red=0.0, green=0.0, blue=0.0):  # lib.lua:166-176
     return Expr("rgb", red=red, green=green, blue=blue)
 
 
-def texture(path, *modifiers):  # lib.lua:178-195 -- accepted by the surface, rejected by the compiler (out of scope)
+def texture(path, *modifiers):  # lib.lua:178-195; `path` may also be an image array (generated textures)
     props = {"path": path, "linear": "linear" in modifiers, "mono": "mono" in modifiers}
     return Expr("mono_texture" if props["mono"] else "color_texture", **props)
 

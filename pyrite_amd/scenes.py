@@ -298,3 +298,55 @@ def lamps_example(width=96, height=64, pixel_samples=16):
         "camera": camera.perspective(fov=45, transform=transform.look_at(**{"from": vector(0, -7, 2.5), "to": vector(0, 0, 0.8), "up": vector(z=1)})),
         "world": {"sky": light_source.d65 * 0.2, "objects": objects},
     }
+
+
+def _generated_textures(seed=3, size=16):
+    """Small seeded images standing in for texture files: an sRGB checker, a smooth 16-bit height-like mono image and a
+    tangent-space normal map (linear RGB, blue-ish), so that tests need no image files."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    checker = np.where(((xx // 2 + yy // 2) % 2)[..., None] == 0, np.array([230, 60, 40]), np.array([40, 90, 220])).astype(np.uint8)
+    checker = np.clip(checker.astype(int) + rng.integers(-20, 20, checker.shape), 0, 255).astype(np.uint8)
+    mono = (32768 + 20000 * np.sin(xx * 0.9) * np.cos(yy * 0.7) + rng.integers(-3000, 3000, (size, size))).astype(np.uint16)
+    bump = rng.normal(0.0, 0.25, (size, size, 2))
+    nz = np.sqrt(np.clip(1.0 - (bump ** 2).sum(-1), 0.05, 1.0))
+    normal_map = np.clip((np.concatenate([bump, nz[..., None]], -1) * 0.5 + 0.5) * 255.0, 0, 255).astype(np.uint8)
+    rgba = np.concatenate([checker, rng.integers(100, 255, (size, size, 1)).astype(np.uint8)], -1)
+    return {"checker": checker, "mono": mono, "normal_map": normal_map, "rgba": rgba}
+
+
+def textures_example(width=96, height=64, pixel_samples=8):
+    """What pyrite/test/textures exercises (the directory is not in the reference checkout): colour and mono textures on a
+    plane, a sphere and a uv-mapped mesh, normal maps on all three shape kinds, a textured emissive sphere (the light
+    sample's texture coordinates, lamp.rs:64-77) -- texture.rs:87-150, execution_context.rs:114-139,
+    materials/mod.rs:68-80, shapes/mod.rs:346-385 / :454-469 / :550-558, world.rs:308-374."""
+    from .project import light, light_source, mix, rgb, texture
+
+    tex = _generated_textures()
+    checker, mono, nmap, rgba = tex["checker"], tex["mono"], tex["normal_map"], tex["rgba"]
+    # a uv-mapped, slightly tilted quad (two triangles) with its own vertex normals
+    quad = {
+        "position": np.array([[-1.5, 1.0, 0.2], [0.5, 1.0, 0.2], [0.5, 2.6, 1.4], [-1.5, 2.6, 1.4]], dtype=f32),
+        "texture": np.array([[0, 0], [2, 0], [2, 1.5], [0, 1.5]], dtype=f32),
+        "normal": np.array([[0, -0.6, 0.8], [0.1, -0.6, 0.8], [0, -0.55, 0.83], [-0.1, -0.6, 0.8]], dtype=f32),
+        "objects": [{"name": "quad", "polys": [[(0, 0, 0), (1, 1, 1), (2, 2, 2)], [(0, 0, 0), (2, 2, 2), (3, 3, 3)]]}],
+    }
+    objects = [
+        shape.plane(origin=vector(0, 0, 0), normal=vector(z=1), texture_scale=vector(1.5, 2.5),
+                    material={"surface": material.diffuse(color=texture(checker) * 0.9), "normal_map": texture(nmap, "linear")}),
+        shape.sphere(position=vector(-1.6, -0.4, 0.9), radius=0.9, texture_scale=vector(0.25, 0.5),
+                     material={"surface": material.diffuse(color=texture(rgba)), "normal_map": texture(nmap, "linear")}),
+        shape.sphere(position=vector(1.5, 0.2, 0.7), radius=0.7,
+                     material={"surface": mix(material.mirror(color=1), material.diffuse(color=rgb(0.9, 0.8, 0.3)), texture(mono, "mono", "linear"))}),
+        shape.mesh(file=quad, transform=transform.look_at(**{"from": vector(0.3, 0.2, 0), "to": vector(0.3, 0.2, -1), "up": vector(0.1, 1, 0)}),
+                   scale=1.1, materials={"quad": {"surface": material.diffuse(color=texture(checker)), "normal_map": texture(nmap, "linear")}}),
+        shape.sphere(position=vector(0.2, -1.4, 2.6), radius=0.35, texture_scale=vector(0.5, 0.5),
+                     material={"surface": material.emissive(color=light_source.d65 * texture(mono, "mono") * 25)}),
+        light.point(position=vector(3, -3, 4), color=light_source.a * 6),
+    ]
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": renderer.simple(pixel_samples=pixel_samples, light_samples=2, bounces=5, tile_size=16, spectrum_samples=6, spectrum_bins=24),
+        "camera": camera.perspective(fov=50, transform=transform.look_at(**{"from": vector(0, -6, 2.6), "to": vector(0, 0, 0.8), "up": vector(z=1)})),
+        "world": {"sky": light_source.d65 * 0.15, "objects": objects},
+    }

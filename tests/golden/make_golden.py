@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures in this directory with the CPU oracle (oracle/liboracle.so).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]
 
 The reference cannot run here (Rust, no toolchain) and has no vectors of its own, so these fixtures pin the ORACLE's
 output (inputs: the scene builders in pyrite_amd/scenes.py + seeds; outputs: film grains and ray hits) so that a
@@ -32,6 +32,7 @@ CASES = {
     "spheres_example": lambda: scenes.spheres_example(width=24, height=12, pixel_samples=8),
     "diamonds_example": lambda: scenes.diamonds_example(width=16, height=10, pixel_samples=8, bounces=16),
     "lamps_example": lambda: scenes.lamps_example(width=18, height=12, pixel_samples=8),
+    "textures_example": lambda: scenes.textures_example(width=18, height=12, pixel_samples=8),
 }
 SEED = 3
 
@@ -53,7 +54,7 @@ def build_case(name):
 
 
 def main():
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):  # name the cases to regenerate, or none for all
         project = build_case(name)
         world, cam, r, film = scenes.build(project, seed=SEED)
         sc = oracle.OracleScene(world)

@@ -78,6 +78,10 @@ def lib():
         L.oracle_run_program.argtypes = [C.c_void_p, C.c_uint32, C.c_float, F3, F3, C.c_float * 2, C.POINTER(C.c_int)]
         L.oracle_run_program.restype = C.c_float
         L.oracle_film_develop.argtypes = [C.POINTER(abi.PyrFilmDesc), C.c_void_p, C.POINTER(abi.PyrDevelopParams), C.c_void_p]
+        L.oracle_texture_get.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_quat_from_cols.argtypes = [F3, F3, F3, C.c_float * 4]
+        L.oracle_quat_rotate.argtypes = [C.c_float * 4, F3, F3]
+        L.oracle_surface_data.argtypes = [C.c_void_p, F6, C.c_float, F3, C.c_float * 2, C.c_float * 4, F3]
         _lib = L
     return _lib
 
@@ -93,6 +97,27 @@ def film_develop(film, step_size=2.0, filter=None, white=None):
     _check(lib().oracle_film_develop(C.byref(desc), grains.ctypes.data, C.byref(p), out.ctypes.data))
     del keep
     return out
+
+
+def texture_get(texels, x, y):
+    """texels: float32 [h, w] (mono) or [h, w, 4] (colour)."""
+    texels = np.ascontiguousarray(texels, dtype=np.float32)
+    channels = 1 if texels.ndim == 2 else texels.shape[2]
+    out = np.zeros(channels, dtype=np.float32)
+    lib().oracle_texture_get(channels, texels.shape[1], texels.shape[0], texels.ctypes.data, x, y, out.ctypes.data)
+    return out
+
+
+def quat_from_cols(c0, c1, c2):
+    out = (C.c_float * 4)()
+    lib().oracle_quat_from_cols(F3(*c0), F3(*c1), F3(*c2), out)
+    return np.array(out[:], dtype=np.float32)
+
+
+def quat_rotate(q, v):
+    out = F3()
+    lib().oracle_quat_rotate((C.c_float * 4)(*q), F3(*v), out)
+    return np.array(out[:], dtype=np.float32)
 
 
 class OracleError(RuntimeError):
@@ -131,6 +156,13 @@ class OracleScene:
         counters = abi.PyrCounters()
         _check(lib().oracle_intersect(self.handle, rays.ctypes.data, len(rays), hits.ctypes.data, C.byref(counters)))
         return hits, counters.as_dict()
+
+    def surface_data(self, ray, wavelength=550.0):
+        """(normal, texture, frame quaternion, shading normal after the normal map) at the ray's first hit, or None."""
+        n, t, f, sn = F3(), (C.c_float * 2)(), (C.c_float * 4)(), F3()
+        if not lib().oracle_surface_data(self.handle, F6(*[float(x) for x in ray]), wavelength, n, t, f, sn):
+            return None
+        return np.array(n[:], dtype=np.float32), np.array(t[:], dtype=np.float32), np.array(f[:], dtype=np.float32), np.array(sn[:], dtype=np.float32)
 
     def bvh_nodes(self):
         n = lib().oracle_bvh_num_nodes(self.handle)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pyrite_gpu.h")
 
 STRUCTS = ["PyrGrain", "PyrFilmDesc", "PyrRenderParams", "PyrCamera", "PyrOperand", "PyrInstr", "PyrProgram", "PyrSpectrum", "PyrComponent",
-           "PyrMaterial", "PyrLamp", "PyrSceneDesc", "PyrCounters", "PyrHit", "PyrBvhInfo", "PyrDevelopParams"]
+           "PyrMaterial", "PyrLamp", "PyrTexture", "PyrSceneDesc", "PyrCounters", "PyrHit", "PyrBvhInfo", "PyrDevelopParams"]
 
 
 @pytest.fixture(scope="module")

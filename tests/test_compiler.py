@@ -59,12 +59,12 @@ def test_rgb_expression_is_converted_through_the_basis():
     assert flat.programs[p]["rgbs"] == 3 and flat.programs[p]["numbers"] == 1
 
 
-def test_vector_cannot_be_a_colour_and_textures_are_out_of_scope():
+def test_vector_cannot_be_a_colour_and_a_missing_texture_file_is_an_error():
     flat = FlatScene()
     with pytest.raises(ProjectError, match="vector as a number"):
         flat.compile(vector(1, 2, 3) * 2)
-    with pytest.raises(ProjectError, match="out of scope"):
-        flat.compile(texture("x.png"))
+    with pytest.raises(ProjectError, match="could not load .* as color texture"):  # textures.rs:78-83
+        flat.compile(texture("no_such_file.png"))
 
 
 def test_mix_material_probabilities():

@@ -73,6 +73,7 @@ CASES = {
     "spheres_example": lambda: scenes.spheres_example(96, 48, 16),
     "diamonds_example": lambda: scenes.diamonds_example(64, 40, 8, bounces=32),
     "lamps_example": lambda: scenes.lamps_example(72, 48, 16),
+    "textures_example": lambda: scenes.textures_example(72, 48, 8),
 }
 
 
@@ -86,7 +87,7 @@ def test_render_matches_the_oracle(name, gpu_lib):
 
 
 @pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
-@pytest.mark.parametrize("name", ["c2_cornell", "lamps_example", "diamonds_example"])
+@pytest.mark.parametrize("name", ["c2_cornell", "lamps_example", "diamonds_example", "textures_example"])
 def test_all_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypatch):
     """The bounce-synchronous walk, the stage-scheduled state machine and the wavefront pipeline are three schedules of the
     same per-path work: all must reproduce the oracle (the library picks one per scene; PYRITE_SCHEDULER forces it)."""
@@ -220,7 +221,7 @@ def test_short_lds_stack_spills_to_scratch_without_changing_results(levels, gpu_
     assert_parity(gfilm, cfilm)
 
 
-@pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example"])
+@pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example", "textures_example"])
 def test_gpu_reproduces_the_committed_golden_films(name, gpu_lib):
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
     mg = importlib.util.module_from_spec(spec)

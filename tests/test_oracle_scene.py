@@ -129,7 +129,7 @@ def test_film_window_keeps_only_its_rows():
     assert only_row1.grains[:7].sum() == 0 and only_row1.grains[17:].sum() == 0  # leaks never travel further than one row
 
 
-@pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example"])
+@pytest.mark.parametrize("name", ["c1_spheres", "c2_cornell", "spheres_example", "diamonds_example", "lamps_example", "textures_example"])
 def test_oracle_reproduces_the_committed_golden_films(name):
     import importlib.util
 
