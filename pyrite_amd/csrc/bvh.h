@@ -38,7 +38,10 @@ struct BuiltBvh {
     uint32_t num_leaves = 0;
 };
 
-constexpr uint32_t kMaxLeafPrims = 4;
+#ifndef PYR_MAX_LEAF
+#define PYR_MAX_LEAF 4
+#endif
+constexpr uint32_t kMaxLeafPrims = PYR_MAX_LEAF; // <= 7: the leaf code keeps the count in 3 bits
 constexpr uint32_t kMaxBvhDepth = 40;
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return -1 - (int32_t)((first << 3) | count); }

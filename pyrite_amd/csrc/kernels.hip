@@ -1360,6 +1360,31 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                 const float lamp_probability = 1.0f / (float)S.num_lamps;
                 const f3 nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
                 const float probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                // Companion wavelengths of the unblocked light samples. Without the interpreter a colour program is a function
+                // of the wavelength alone (a constant or spectrum [* c]), so consecutive samples that show the same program
+                // need its value at each companion wavelength only once: their probabilities are parked (up to four) and the
+                // companions are brought up to date in one pass -- each brightness still receives the same addends in the
+                // same order as in `contribute` (algorithm.rs:65-90), so the result is bit-identical, at a quarter of the
+                // spectrum look-ups.
+                float parked0 = 0.0f, parked1 = 0.0f, parked2 = 0.0f, parked3 = 0.0f;
+                uint32_t parked = 0, parked_color = 0;
+                auto flush_parked = [&]() {
+                    if (parked == 0) return;
+                    const Prepared q_prog = prepare_program<INTERP>(S, parked_color);
+                    VmInput in{0.0f, mk(0, 0, 0), mk(0, 0, 0)};
+                    for (uint32_t k = 0; k < n_add; ++k) {
+                        in.wavelength = spec.wl(k);
+                        const float color = eval_prepared<INTERP>(S, q_prog, in);
+                        const float refl = spec.refl(k);
+                        float b = spec.bright(k);
+                        b += color * parked0 * refl;
+                        if (parked > 1) b += color * parked1 * refl;
+                        if (parked > 2) b += color * parked2 * refl;
+                        if (parked > 3) b += color * parked3 * refl;
+                        spec.bright(k) = b;
+                    }
+                    parked = 0;
+                };
                 for (uint32_t ls_i = 0; ls_i < L.light_samples; ++ls_i) {
                     const LampSample ls = lamp_sample(lamp, p.rng, position);
                     const float cos_out = fmaxf(dot(nff, ls.direction), 0.0f);
@@ -1391,12 +1416,24 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                     const Prepared q_prog = prepare_program<INTERP>(S, l_color);
                     VmInput in{p.wl, target_normal, ls.direction};
                     p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
-                    if (p.use_additional && !l_dispersed)
-                        for (uint32_t k = 0; k < n_add; ++k) {
-                            in.wavelength = spec.wl(k);
-                            spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
+                    if (p.use_additional && !l_dispersed) {
+                        if constexpr (INTERP) {
+                            for (uint32_t k = 0; k < n_add; ++k) {
+                                in.wavelength = spec.wl(k);
+                                spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
+                            }
+                        } else {
+                            if (parked != 0 && (parked == 4 || parked_color != l_color)) flush_parked();
+                            parked_color = l_color;
+                            if (parked == 0) parked0 = l_probability;
+                            if (parked == 1) parked1 = l_probability;
+                            if (parked == 2) parked2 = l_probability;
+                            if (parked == 3) parked3 = l_probability;
+                            parked++;
                         }
+                    }
                 }
+                flush_parked();
             }
         }
     } else {
