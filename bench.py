@@ -147,14 +147,22 @@ def main():
         sys.exit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world_size))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # PYRITE_BENCH_REHEARSAL=1 (development): all ranks share the visible GPUs and talk over gloo, to exercise the N > 1
+    # code path on a one-GPU box; the line is marked and is not a measurement of anything.
+    rehearsal = os.environ.get("PYRITE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     builder, width, height, spp = WORKLOADS[args.workload]
-    reduced = args.spp is not None and args.spp != spp
+    reduced = (args.spp is not None and args.spp != spp) or rehearsal
     spp = args.spp or spp
     project = getattr(scenes, builder)(width=width, height=height, pixel_samples=spp)
     world, cam, renderer, _ = scenes.build(project, seed=args.seed)
@@ -167,12 +175,24 @@ def main():
     film_desc = abi.PyrFilmDesc(width, height, bins, renderer.spectrum_span[0], renderer.spectrum_span[1] - renderer.spectrum_span[0])
     stream = torch.cuda.current_stream(device)
 
+    launch_events = []  # (start, stop) HIP events around every render launch of this rank, on the launch stream
+
     def render_window(tile_range, rows, window, flags=0):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
         renderer.render_device(window.data_ptr(), film_desc, cam, world, stream=stream.cuda_stream, device=local_rank, flags=flags,
                                tile_range=tile_range, film_rows=rows)
+        b.record(stream)
+        launch_events.append((a, b))
+
+    # Sharding (pyrite_amd/distributed.py plan): a scene small enough to live in LDS costs about the same everywhere in the
+    # image (C2: slowest of 8 contiguous shares 1.03x the mean), so each rank gets one contiguous band = one launch; a big
+    # scene does not (C3: 1.37x), so its tile rows are dealt round-robin. PYRITE_SHARDING overrides.
+    info0 = world.bvh_info(local_rank)
+    sharding = os.environ.get("PYRITE_SHARDING") or ("contiguous" if world_size == 1 or info0["node_bytes"] + info0["primitive_bytes"] <= 8 * 1024 else "cyclic")
 
     def step():
-        return pdist.render_sharded(render_window, width, height, bins, renderer.tile_size, device)
+        return pdist.render_sharded(render_window, width, height, bins, renderer.tile_size, device, sharding=sharding)
 
     def fence():
         if world_size > 1:
@@ -182,6 +202,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    launch_events.clear()
     start_evt, stop_evt = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     start_evt.record(stream)
@@ -221,7 +242,7 @@ def main():
                 "workload": "%s: %s, %dx%d, %d spp%s" % (args.workload, builder, width, height, spp, " (REDUCED spp: development run)" if reduced else ""),
                 "bounces": renderer.bounces, "light_samples": renderer.light_samples, "spectrum_samples": renderer.spectrum_samples,
                 "spectrum_bins": bins, "tile_size": renderer.tile_size, "triangles": len(world.flat.tri_material), "spheres": len(world.flat.spheres),
-                "parallelism": "tiles sharded over %d GPU(s), one film gather" % world_size,
+                "parallelism": "one launch on one GPU" if world_size == 1 else "%s tile bands on %d GPUs, one film gather" % (sharding, world_size),
                 # samples that map outside the image are dropped as in the reference (film.rs:51-54): a few per 1e7
                 "film_weight": total_weight, "film_weight_expected": expected_weight,
                 "film_weight_check": "ok" if abs(total_weight - expected_weight) <= 1e-5 * expected_weight else "MISMATCH",
@@ -229,15 +250,20 @@ def main():
         }
     del film
 
-    if world_size == 1:
-        # kernel duration from HIP events on the launch stream (one launch per step at N = 1)
-        kernel_ms = start_evt.elapsed_time(stop_evt) / max(args.steps, 1)
-        # algorithmic bytes per launch: instrumented run of the same launch, outside the timed region
-        window = torch.zeros((height, width, bins, 2), dtype=torch.float32, device=device)
-        render_window((0, 0), (0, height), window, flags=abi.PYR_FLAG_COUNTERS)
-        torch.cuda.synchronize(device)
-        counters = renderer.counters(world, local_rank)
-        del window
+    if rank == 0:
+        # kernel duration from HIP events on the launch stream: one launch per step at N = 1, one per band of this rank's
+        # share otherwise (the figure is then rank 0's kernel time and rank 0's algorithmic bytes, i.e. per GPU)
+        kernel_ms = sum(a.elapsed_time(b) for a, b in launch_events) / max(args.steps, 1)
+        # algorithmic bytes per step: instrumented run of the same launches, outside the timed region
+        shares = pdist.plan(width, height, renderer.tile_size, world_size, sharding)
+        counters = None
+        for tile_range, (first_row, rows) in shares[0]:
+            window = torch.zeros((rows, width, bins, 2), dtype=torch.float32, device=device)
+            render_window(tile_range, (first_row, rows), window, flags=abi.PYR_FLAG_COUNTERS)
+            torch.cuda.synchronize(device)
+            c = renderer.counters(world, local_rank)
+            counters = c if counters is None else {k: counters[k] + c[k] for k in c}
+            del window
         info = world.bvh_info(local_rank)
         lds_resident = info["node_bytes"] + info["primitive_bytes"] <= 8 * 1024
         forced = os.environ.get("PYRITE_SCHEDULER")
@@ -255,14 +281,15 @@ def main():
             "traffic": load_traffic(args.workload),
             "kernel": kernel_name,
             "kernel_ms": round(kernel_ms, 3),
+            "launches_per_step": len(shares[0]),
             "algorithmic_bytes_per_launch": int(total),
             "traversal_bytes_per_launch": int(traversal),
             "traversal_frac": round(traversal / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "counters": counters,
         }
-        if not args.no_traversal:
+        if world_size == 1 and not args.no_traversal:
             line["traversal_roofline"] = traversal_roofline(local_rank)
-        if not args.no_cpu_baseline:
+        if world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(world, cam, renderer, width, height)
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -1250,15 +1250,32 @@ DEV bool locate_chunk(const RenderLaunch& L, uint32_t chunk, uint32_t lane, uint
     return true;
 }
 
+// Developer build only (-DPYR_PHASE_PROFILE, tools/phase_profile.py): lap timers of the synchronous walk's sections.
+struct SyncProf {
+    unsigned long long section[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+};
+#ifdef PYR_PHASE_PROFILE
+__device__ unsigned long long g_phase_prof[16];
+#define SLAP(sp, i)                                 \
+    {                                               \
+        const unsigned long long now_ = clock64();  \
+        (sp).section[i] += now_ - (sp).last;        \
+        (sp).last = now_;                           \
+    }
+#else
+#define SLAP(sp, i)
+#endif
+
 // One iteration of tracer::trace's loop (tracer.rs:221-344) with `contribute` (renderer/algorithm.rs:14-100) applied online.
 // Returns true when the path has ended (emission, miss). Does not touch p.bounce.
 template <bool COUNT, bool INTERP>
-DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& view, Path& p, Spectral& spec, int* stack, Counters& cnt) {
+DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& view, Path& p, Spectral& spec, int* stack, Counters& cnt, SyncProf& sp) {
     const uint32_t n_add = L.spectrum_samples - 1;
     Hit hit;
     if (COUNT) cnt.extension_rays++;
     const f3 ray_o = p.o, ray_d = p.d;
     const bool found = traverse<COUNT, false>(S, view.nodes, view.prims, ray_o, ray_d, 0.0f, hit, stack, cnt);
+    SLAP(sp, 1);
     if (!found) {
         // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
         uint32_t color = S.sky_program;
@@ -1349,6 +1366,7 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
             }
     }
 
+    SLAP(sp, 2);
     // next-event estimation gate, tracer.rs:257-280
     if (p.events < 2) {
         p.sample_light = !has_brdf || L.light_samples == 0;
@@ -1392,7 +1410,10 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                     if (COUNT) cnt.shadow_rays++;
                     const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
                     Hit shadow_hit;
-                    if (traverse<COUNT, true>(S, view.nodes, view.prims, position, ls.direction, limit, shadow_hit, stack, cnt)) continue; // blocked
+                    SLAP(sp, 3);
+                    const bool is_blocked = traverse<COUNT, true>(S, view.nodes, view.prims, position, ls.direction, limit, shadow_hit, stack, cnt);
+                    SLAP(sp, 4);
+                    if (is_blocked) continue;
                     uint32_t l_color = ls.color;
                     float material_probability = 1.0f;
                     bool l_dispersed = false;
@@ -1434,6 +1455,7 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                     }
                 }
                 flush_parked();
+                SLAP(sp, 5);
             }
         }
     } else {
@@ -1449,6 +1471,7 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
     }
     p.o = position;
     p.d = out_direction;
+    SLAP(sp, 6);
     return false;
 }
 
@@ -1483,6 +1506,10 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
     const uint32_t wave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const uint32_t total_waves = gridDim.x * waves_per_block;
 
+    SyncProf sp;
+#ifdef PYR_PHASE_PROFILE
+    sp.last = clock64();
+#endif
     for (uint32_t chunk = L.chunk_begin + wave; chunk < L.chunk_end; chunk += total_waves) {
         uint32_t tile;
         uint64_t iteration;
@@ -1491,13 +1518,20 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
         Path p{};
         start_sample(L, tile, iteration, area, p, spec);
         if (COUNT) cnt.samples++;
+        SLAP(sp, 0);
         while (p.bounce < L.bounces) {
-            const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt);
+            const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt, sp);
             p.bounce++;
             if (ended) break;
         }
+        SLAP(sp, 6);
         finish_path<COUNT>(L, p, spec, cnt);
+        SLAP(sp, 7);
     }
+#ifdef PYR_PHASE_PROFILE
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_prof[i], sp.section[i]);
+#endif
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -1517,7 +1551,6 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
 // =================================================================================================
 // Developer build only (-DPYR_PHASE_PROFILE, tools/phase_profile.py): per-phase wave cycles / active lanes / turns.
 #ifdef PYR_PHASE_PROFILE
-__device__ unsigned long long g_phase_prof[16];
 #define PROF_DECL unsigned long long prof_c[4] = {0, 0, 0, 0}, prof_l[4] = {0, 0, 0, 0}, prof_n[4] = {0, 0, 0, 0}
 #define PROF_BEGIN(ph, cond) const unsigned long long prof_t0_##ph = clock64(); prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
 #define PROF_END(ph) prof_c[ph] += clock64() - prof_t0_##ph

@@ -21,13 +21,22 @@ def test_partition_and_windows():
     assert pdist.partition_tiles(2040, 8) == [(255 * r, 255 * (r + 1)) for r in range(8)]
     assert pdist.partition_tiles(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert pdist.partition_tiles(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
-    # 1920x1080, 32-pixel tiles: 60 x 34 tiles; rank 1 of 8 starts mid-row 4 and ends mid-row 8
-    (rng, (lo, rows)) = pdist.plan(1920, 1080, 32, 8)[1]
+    # 1920x1080, 32-pixel tiles: 60 x 34 tiles; contiguous: rank 1 of 8 starts mid-row 4 and ends mid-row 8
+    ((rng, (lo, rows)),) = pdist.plan(1920, 1080, 32, 8, "contiguous")[1]
     assert rng == (255, 510) and lo == 4 * 32 - 1 and lo + rows == 9 * 32 + 1
-    (rng, (lo, rows)) = pdist.plan(1920, 1080, 32, 8)[7]
+    ((rng, (lo, rows)),) = pdist.plan(1920, 1080, 32, 8, "contiguous")[7]
     assert lo + rows == 1080  # clamped at the image edge
-    assert pdist.plan(64, 64, 32, 1) == [((0, 4), (0, 64))]
+    assert pdist.plan(64, 64, 32, 1) == [[((0, 4), (0, 64))]]
     assert pdist.window_rows((2, 2), 2, 32, 64) == (0, 0)
+    assert pdist.plan(64, 32, 32, 4, "contiguous")[3] == []  # two tiles, four ranks: the last two have nothing to do
+    # cyclic (the default for more than one rank): tile row ty goes to rank ty % N, one band per tile row
+    shares = pdist.plan(1920, 1080, 32, 8)
+    assert [len(s) for s in shares] == [5, 5, 4, 4, 4, 4, 4, 4]
+    assert shares[1][0] == ((60, 120), (31, 34)) and shares[0][0] == ((0, 60), (0, 33))
+    assert shares[1][4] == ((33 * 60, 34 * 60), (33 * 32 - 1, 1080 - 33 * 32 + 1))  # the last, 24-pixel tile row
+    every = sorted(rng for share in shares for rng, _ in share)
+    assert every == [(ty * 60, (ty + 1) * 60) for ty in range(34)]  # each tile row exactly once
+    assert pdist.window_height(shares[0]) == 33 + 4 * 34
 
 
 def _free_port():
@@ -36,7 +45,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world_size, port, out_path):
+def _worker(rank, world_size, port, out_path, sharding):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle
@@ -51,11 +60,11 @@ def _worker(rank, world_size, port, out_path):
         sc = oracle.OracleScene(world)
 
         def render_window(tile_range, rows, window):
-            view = window.numpy()[: rows[1]]
-            assert view.flags["C_CONTIGUOUS"]
+            view = window.numpy()
+            assert view.flags["C_CONTIGUOUS"] and view.shape[0] == rows[1]
             sc.render(r, cam, film, threads=1, tile_range=tile_range, film_rows=rows, window=view)
 
-        result = pdist.render_sharded(render_window, film.width, film.height, film.bins, r.tile_size, torch.device("cpu"))
+        result = pdist.render_sharded(render_window, film.width, film.height, film.bins, r.tile_size, torch.device("cpu"), sharding=sharding)
         if rank == 0:
             np.save(out_path, result.numpy())
         else:
@@ -64,14 +73,14 @@ def _worker(rank, world_size, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size", [2, 3])
-def test_two_gloo_ranks_reproduce_the_single_process_film(world_size):
+@pytest.mark.parametrize("world_size,sharding", [(2, "cyclic"), (3, "cyclic"), (2, "contiguous"), (3, "contiguous")])
+def test_gloo_ranks_reproduce_the_single_process_film(world_size, sharding):
     import oracle
     from pyrite_amd import scenes
 
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "film.npy")
-        mp.spawn(_worker, args=(world_size, _free_port(), out), nprocs=world_size, join=True)
+        mp.spawn(_worker, args=(world_size, _free_port(), out, sharding), nprocs=world_size, join=True)
         sharded = np.load(out)
     world, cam, r, film = scenes.build(scenes.c2_cornell(40, 36, 2), seed=7)
     r.tile_size = 8

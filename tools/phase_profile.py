@@ -33,6 +33,14 @@ t = time.time()
 r.render(film, cam, world)
 dt = time.time() - t
 fn(out, 1)
+if which == "C2" and os.environ.get("PYRITE_SCHEDULER", "sync") == "sync":  # the synchronous walk: lap timers of lane 0 of every wave
+    names = ["start_sample", "extension traversal", "shade (surface, scatter, reflectance)", "light sample", "shadow traversal",
+             "light accounting", "bounce tail / ended lanes", "expose"]
+    total = float(sum(out[0:8])) or 1.0
+    print("%s %dx%d x %d spp: %.3f s incl. film transfer" % (which, w, h, spp, dt))
+    for name, c in zip(names, out[0:8]):
+        print("%-40s %5.1f %% of wave cycles" % (name, 100.0 * c / total))
+    sys.exit(0)
 cyc, lanes, turns = list(out[0:4]), list(out[4:8]), list(out[8:12])
 total = float(sum(cyc)) or 1.0
 samples = w * h * spp

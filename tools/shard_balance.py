@@ -23,18 +23,23 @@ world_.scene(0)
 dev = torch.device("cuda", 0)
 desc = abi.PyrFilmDesc(W, H, r.spectrum_bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
 stream = torch.cuda.current_stream(dev)
-shares = pdist.plan(W, H, r.tile_size, world)
-times = []
-for tile_range, (first_row, rows) in shares:
-    window = torch.zeros((rows, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
-    ms = 0.0
-    for _ in range(2):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        r.render_device(window.data_ptr(), desc, cam, world_, stream=stream.cuda_stream, device=0, tile_range=tile_range, film_rows=(first_row, rows))
-        b.record(stream)
-        torch.cuda.synchronize(dev)
-        ms = a.elapsed_time(b)
-    times.append(ms)
-    print("tiles %s rows %d+%d: %.2f ms" % (tile_range, first_row, rows, ms), flush=True)
-print("max / mean = %.3f  (ideal strong-scaling efficiency bound %.3f)" % (max(times) / (sum(times) / len(times)), (sum(times) / len(times)) / max(times)))
+for sharding in ("contiguous", "cyclic"):
+    shares = pdist.plan(W, H, r.tile_size, world, sharding)
+    times = []
+    for share in shares:
+        total = 0.0
+        for tile_range, (first_row, rows) in share:
+            window = torch.zeros((rows, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+            ms = 0.0
+            for _ in range(2):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                r.render_device(window.data_ptr(), desc, cam, world_, stream=stream.cuda_stream, device=0, tile_range=tile_range, film_rows=(first_row, rows))
+                b.record(stream)
+                torch.cuda.synchronize(dev)
+                ms = a.elapsed_time(b)
+            total += ms
+        times.append(total)
+    mean = sum(times) / len(times)
+    print("%-10s per-rank ms: %s | max / mean = %.3f (strong-scaling efficiency bound %.3f)"
+          % (sharding, " ".join("%.1f" % t for t in times), max(times) / mean, mean / max(times)), flush=True)
