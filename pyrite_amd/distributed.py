@@ -50,9 +50,8 @@ def plan(width, height, tile_size, world_size, sharding=None):
 
     "contiguous": one band per rank, equal tile counts. Cheapest (one launch, one halo) but only balanced when cost is
     uniform over the image: on C3 the rows that show the mesh cost 1.6x the others and the slowest of 8 ranks takes 1.37x
-    the mean.  "cyclic": tile rows are dealt round-robin, one band per tile row, so every rank sees every part of the
-    image (C3, 8 ranks: 1.14x the mean, the remainder being 34 rows over 8 ranks); windows grow by the extra halos
-    (34 / 32). Default: contiguous for one rank, cyclic otherwise; PYRITE_SHARDING=contiguous|cyclic overrides."""
+    the mean.  "cyclic": tile rows (cut into pieces when there are few rows per rank) are dealt round-robin, so
+    every rank sees every part of the image; windows grow by the extra halos (34 / 32) and by the row pieces. Default: contiguous for one rank, cyclic otherwise; PYRITE_SHARDING=contiguous|cyclic overrides."""
     import os
 
     tiles_x, tiles_y = tile_grid(width, height, tile_size)
@@ -62,10 +61,17 @@ def plan(width, height, tile_size, world_size, sharding=None):
         return [[(rng, window_rows(rng, tiles_x, tile_size, height))] if rng[1] > rng[0] else [] for rng in ranges]
     if sharding != "cyclic":
         raise ValueError("unknown sharding %r" % (sharding,))
+    # bands = tile rows, cut into `splits` pieces each when there are fewer than ~8 rows per rank (34 rows on 8 ranks would
+    # leave two ranks with 5 rows against 4); a piece still needs the full-width rows of its tile row as window
+    splits = max(1, min(tiles_x, -(-8 * world_size // tiles_y)))
     shares = [[] for _ in range(world_size)]
+    k = 0
     for ty in range(tiles_y):
-        rng = (ty * tiles_x, (ty + 1) * tiles_x)
-        shares[ty % world_size].append((rng, window_rows(rng, tiles_x, tile_size, height)))
+        for piece in range(splits):
+            a, b = ty * tiles_x + tiles_x * piece // splits, ty * tiles_x + tiles_x * (piece + 1) // splits
+            if b > a:
+                shares[k % world_size].append(((a, b), window_rows((a, b), tiles_x, tile_size, height)))
+                k += 1
     return shares
 
 

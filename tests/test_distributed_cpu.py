@@ -29,14 +29,17 @@ def test_partition_and_windows():
     assert pdist.plan(64, 64, 32, 1) == [[((0, 4), (0, 64))]]
     assert pdist.window_rows((2, 2), 2, 32, 64) == (0, 0)
     assert pdist.plan(64, 32, 32, 4, "contiguous")[3] == []  # two tiles, four ranks: the last two have nothing to do
-    # cyclic (the default for more than one rank): tile row ty goes to rank ty % N, one band per tile row
-    shares = pdist.plan(1920, 1080, 32, 8)
-    assert [len(s) for s in shares] == [5, 5, 4, 4, 4, 4, 4, 4]
-    assert shares[1][0] == ((60, 120), (31, 34)) and shares[0][0] == ((0, 60), (0, 33))
-    assert shares[1][4] == ((33 * 60, 34 * 60), (33 * 32 - 1, 1080 - 33 * 32 + 1))  # the last, 24-pixel tile row
-    every = sorted(rng for share in shares for rng, _ in share)
-    assert every == [(ty * 60, (ty + 1) * 60) for ty in range(34)]  # each tile row exactly once
-    assert pdist.window_height(shares[0]) == 33 + 4 * 34
+    # cyclic (the default for more than one rank): tile rows dealt round-robin, cut in pieces when rows per rank are few
+    shares = pdist.plan(1920, 1080, 32, 2)
+    assert [len(s) for s in shares] == [17, 17] and shares[1][0] == ((60, 120), (31, 34)) and shares[0][0] == ((0, 60), (0, 33))
+    assert shares[1][16] == ((33 * 60, 34 * 60), (33 * 32 - 1, 1080 - 33 * 32 + 1))  # the last, 24-pixel tile row
+    shares = pdist.plan(1920, 1080, 32, 8)  # 34 rows on 8 ranks: half rows, 68 bands
+    assert sorted(len(s) for s in shares) == [8, 8, 8, 8, 9, 9, 9, 9]
+    assert shares[0][0] == ((0, 30), (0, 33)) and shares[1][0] == ((30, 60), (0, 33)) and shares[2][0] == ((60, 90), (31, 34))
+    for n in (2, 3, 8):
+        tiles = sorted(rng for share in pdist.plan(1920, 1080, 32, n) for rng, _ in share)
+        assert tiles[0][0] == 0 and tiles[-1][1] == 2040 and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))  # every tile once
+    assert pdist.window_height(pdist.plan(1920, 1080, 32, 2)[0]) == 33 + 16 * 34
 
 
 def _free_port():
