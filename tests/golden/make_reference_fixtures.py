@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Turn the rendered example images the reference keeps next to its test projects into small numeric fixtures.
+
+    python tests/golden/make_reference_fixtures.py        (needs /root/reference; the fixtures are committed)
+
+pyrite/test/spheres/hq_example.png and pyrite/test/diamonds/hq_example.png were rendered by the reference itself with the
+`simple` renderer (spheres.lua: 512x256, 600 spp; diamonds.lua: 512x300, 200 spp, 256 bounces, thin lens, dispersion).
+They are the only outputs of the reference that exist for this path. Each is reduced to linear-light RGB block means
+(8 x 8 pixels, sRGB decoded) -- data, a few KB -- against which tests/test_reference_images.py holds the oracle with a
+loose tolerance: the images predate the current film-development code (their colour rendition differs slightly from what
+main.rs:315-418 produces today), so only luminance structure and level are compared."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from pyrite_amd import images  # noqa: E402
+
+REFERENCE = "/root/reference/pyrite/test"
+BLOCK = 8
+
+
+def block_means(rgb8, block=BLOCK):
+    lin = images.srgb_to_linear(rgb8[..., :3].astype(np.float64) / 255.0).astype(np.float64)
+    h, w = lin.shape[0] // block * block, lin.shape[1] // block * block
+    return lin[:h, :w].reshape(h // block, block, w // block, block, 3).mean((1, 3)).astype(np.float32)
+
+
+def main():
+    out = {}
+    for name in ("spheres", "diamonds"):
+        img = images.read_png(os.path.join(REFERENCE, name, "hq_example.png"))
+        out[name] = block_means(img)
+        out[name + "_size"] = np.array(img.shape[:2][::-1])
+        print(name, img.shape, "->", out[name].shape)
+    np.savez_compressed(os.path.join(HERE, "reference_example_images.npz"), block=BLOCK, **out)
+
+
+if __name__ == "__main__":
+    main()
