@@ -11,10 +11,11 @@
  * from OS entropy, so no numeric output of the reference exists to pin this restatement against. It is written
  * line by line from the cited sources; third-party arithmetic (collision, cgmath, rand, palette) is
  * restated from the published algorithms of the pinned versions in Cargo.lock and labelled as such.
- * WEAK PIN: the two example images the reference rendered with this renderer (pyrite/test/spheres and
- * pyrite/test/diamonds hq_example.png, reduced to block means in tests/golden/reference_example_images.npz) are
- * reproduced in luminance level and structure (diamonds: 0.96x mean luminance, correlation 0.999 at the project's own
- * 200 spp x 256 bounces; spheres: floor luminance 0.90x) -- tests/test_reference_images.py.
+ * WEAK PIN: the three example images the reference rendered with this renderer (pyrite/test/{spheres,diamonds,textures}/
+ * hq_example.png, reduced to 8 x 8 block means in tests/golden/reference_example_images.npz) are reproduced:
+ * textures -- correlation 0.997, median luminance ratio 0.99, colour-checker patches within a few percent per channel;
+ * diamonds -- 0.96x mean luminance, correlation 0.999 at the project's own 200 spp x 256 bounces; spheres (an older
+ * image) -- floor luminance 0.90x. tests/test_reference_images.py.
  *
  * It consumes the same plain-data scene description as the product (include/pyrite_gpu.h) -- the data
  * format is shared, no code is.

@@ -350,3 +350,39 @@ def textures_example(width=96, height=64, pixel_samples=8):
         "camera": camera.perspective(fov=50, transform=transform.look_at(**{"from": vector(0, -6, 2.6), "to": vector(0, 0, 0.8), "up": vector(z=1)})),
         "world": {"sky": light_source.d65 * 0.15, "objects": objects},
     }
+
+
+def textures_reference_example(texture_dir, width=1024, height=512, pixel_samples=400):
+    """pyrite/test/textures/textures.lua:1-91 (simple renderer): a mirror / textured-diffuse fresnel mix floor with a normal
+    map on a plane, two D65 ball lamps, the uv-mapped colour-checker quad, a textured + normal-mapped sphere and a cube. The
+    texture images come from `texture_dir` (tests/golden/textures holds shrunk copies); the cube's `fabric` textures are
+    not in the reference checkout, so the cube is plain diffuse here."""
+    from .project import fresnel, light_source, mix, texture
+
+    def tex(name, *modifiers):
+        return texture(os.path.join(texture_dir, name), *modifiers)
+
+    light_ball = shape.sphere(material={"surface": material.emissive(color=light_source.d65 * 20)}, position=vector(0, 0, 0), radius=1)
+    floor_material = {
+        "surface": mix(material.mirror(color=1), material.diffuse(color=tex("tiles_color.png")), fresnel(1.5)),
+        "normal_map": tex("tiles_normal.png", "linear") * vector(1, -1, 1),
+    }
+    objects = [
+        shape.plane(origin=vector(), normal=vector(y=1), material=floor_material, texture_scale=5),
+        light_ball.with_(position=vector(-1, 12, 2), radius=3),
+        light_ball.with_(position=vector(15, 3, 4)),
+        shape.mesh(file=os.path.join(texture_dir, "color_checker.obj"),
+                   materials={"color_checker": {"surface": material.diffuse(color=tex("color_checker.png"))}}),
+        shape.sphere(position=vector(-3, 1, 0), radius=1, texture_scale=vector(0.5, 1),
+                     material={"surface": material.diffuse(color=tex("tactile_paving_color.png")),
+                               "normal_map": tex("tactile_paving_normal.png", "linear") * vector(1, -1, 1)}),
+        shape.mesh(file=os.path.join(texture_dir, "cube.obj"),
+                   transform=transform.look_at(**{"from": vector(2, 0.5, 1), "to": vector(-1, 0.5, 2)}),
+                   materials={"cube": {"surface": material.diffuse(color=0.6)}}),
+    ]
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": renderer.simple(pixel_samples=pixel_samples, spectrum_samples=10, spectrum_bins=50, tile_size=32, bounces=8, light_samples=2),
+        "camera": camera.perspective(fov=53, transform=transform.look_at(**{"from": vector(0, 2, 12), "to": vector(0, 2, 0)})),
+        "world": {"objects": objects},
+    }

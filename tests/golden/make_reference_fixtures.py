@@ -29,9 +29,53 @@ def block_means(rgb8, block=BLOCK):
     return lin[:h, :w].reshape(h // block, block, w // block, block, 3).mean((1, 3)).astype(np.float32)
 
 
+def decode_jpeg(path):
+    """Baseline JPEG -> uint8 [h, w, 3] through tools/jpeg_decode.c (the container has no image library)."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(tempfile.gettempdir(), "pyrite_jpeg_decode")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "jpeg_decode.c"), "-lm"])
+    with tempfile.NamedTemporaryFile(suffix=".ppm") as tmp:
+        subprocess.check_call([exe, path, tmp.name])
+        raw = open(tmp.name, "rb").read()
+    header = raw.split(b"\n", 3)
+    w, h = (int(x) for x in header[1].split())
+    return np.frombuffer(header[3], dtype=np.uint8).reshape(h, w, 3)
+
+
+def shrink(img, factor):
+    """Box filter on the 8-bit values (what an image editor's resize does), rounded back to 8 bits."""
+    h, w = img.shape[0] // factor * factor, img.shape[1] // factor * factor
+    small = img[:h, :w].reshape(h // factor, factor, w // factor, factor, 3).astype(np.float64).mean((1, 3))
+    return np.clip(np.floor(small + 0.5), 0, 255).astype(np.uint8)
+
+
+def texture_fixtures():
+    """test/textures: the texture images shrunk to a few tens of KB each (the render is compared in 8 x 8 pixel blocks, far
+    coarser than the texture detail that is lost) and the two small meshes re-emitted by this script's own writer. The
+    `fabric` textures of the cube are not in the reference checkout (.MISSING_LARGE_BLOBS)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from extract_reference_data import reemit_obj
+    from pyrite_amd import develop
+
+    out_dir = os.path.join(HERE, "textures")
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(REFERENCE, "textures")
+    for rel, factor in (("color_checker.jpg", 4), ("tiles/color.jpg", 16), ("tiles/normal.jpg", 16), ("tactile_paving/color.jpg", 16),
+                        ("tactile_paving/normal.jpg", 16)):
+        img = shrink(decode_jpeg(os.path.join(src, rel)), factor)
+        name = rel.replace("/", "_").replace(".jpg", ".png")
+        develop.save_png(os.path.join(out_dir, name), img)
+        print(rel, "->", name, img.shape, os.path.getsize(os.path.join(out_dir, name)), "bytes")
+    for name in ("color_checker.obj", "cube.obj"):
+        reemit_obj(os.path.join(src, name), os.path.join(out_dir, name), "test/textures " + name)
+
+
 def main():
     out = {}
-    for name in ("spheres", "diamonds"):
+    texture_fixtures()
+    for name in ("spheres", "diamonds", "textures"):
         img = images.read_png(os.path.join(REFERENCE, name, "hq_example.png"))
         out[name] = block_means(img)
         out[name + "_size"] = np.array(img.shape[:2][::-1])

@@ -61,6 +61,35 @@ def test_diamonds_example_matches_the_reference_image():
     assert 0.8 < np.median(ym[cells] / yr[cells]) < 1.15
 
 
+TEXTURES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures")
+# colour-checker patches (8 x 8 pixel cells of the 1024 x 512 image: row, column) and the cube, whose textures are missing
+PATCHES = {"brown": (19, 65), "orange": (25, 65), "blue": (31, 65), "white": (38, 65), "green": (31, 71), "red": (31, 77), "yellow": (31, 83),
+           "cyan": (31, 98)}
+CUBE = (slice(40, 58), slice(76, 98))
+
+
+def check_textures_image(mine, ref):
+    yr, ym = ref @ LUMA, mine @ LUMA
+    mask = np.ones_like(yr, dtype=bool)
+    mask[CUBE] = False
+    assert np.corrcoef(yr[mask], ym[mask])[0, 1] > 0.99  # measured 0.997
+    cells = mask & (yr > 0.02) & (yr < 0.9)
+    assert 0.9 < np.median(ym[cells] / yr[cells]) < 1.1  # measured 0.99
+    for name, (y, x) in PATCHES.items():  # texture lookup, sRGB decoding, RGB -> spectrum, lamps, development: all in one number
+        assert np.allclose(mine[y, x], ref[y, x], rtol=0.15, atol=0.02), (name, mine[y, x], ref[y, x])
+
+
+def test_textures_example_matches_the_reference_image():
+    """pyrite/test/textures: colour textures on a quad, a plane and a sphere, normal maps on plane and sphere, a fresnel mix
+    of mirror and textured diffuse. This image was rendered by the current development code, so colours are comparable:
+    the colour-checker patches come out within a few percent per channel (brown 0.124 0.044 0.022 vs 0.124 0.043 0.022)."""
+    data = np.load(GOLDEN)
+    ref = data["textures"].astype(np.float64)  # 64 x 128 cells
+    mine = oracle_block_means(scenes.textures_reference_example(TEXTURES, 512, 256, 48), 4)
+    assert mine.shape == ref.shape == (64, 128, 3)
+    check_textures_image(mine, ref)
+
+
 @pytest.mark.gpu
 def test_gpu_renders_match_the_reference_images(gpu_lib):
     """The HIP path at the projects' own sizes and sample counts (512 x 256 x 600 spp, 512 x 300 x 200 spp x 256 bounces),
@@ -83,3 +112,7 @@ def test_gpu_renders_match_the_reference_images(gpu_lib):
             assert 0.8 < np.median(ym[floor] / yr[floor]) < 1.1
         else:
             assert 0.85 < ym.mean() / yr.mean() < 1.1
+    world, cam, r, film = scenes.build(scenes.textures_reference_example(TEXTURES, 1024, 512, 400), seed=1)
+    r.render(film, cam, world)
+    lin = images.srgb_to_linear(develop.develop(film).astype(np.float64) / 255.0).astype(np.float64)
+    check_textures_image(lin.reshape(64, 8, 128, 8, 3).mean((1, 3)), data["textures"].astype(np.float64))
