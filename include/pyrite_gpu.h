@@ -153,8 +153,8 @@ typedef struct PyrInstr {
 } PyrInstr; /* 64 bytes */
 
 #define PYR_MAX_NUMBER_REGISTERS 16
-#define PYR_MAX_VECTOR_REGISTERS 4
-#define PYR_MAX_RGB_REGISTERS 4
+#define PYR_MAX_VECTOR_REGISTERS 8
+#define PYR_MAX_RGB_REGISTERS 8
 
 /* ProgramType (program/mod.rs:61-73): Constant short-circuits, Instructions reads one output register. */
 typedef enum PyrProgramKind { PYR_PROGRAM_CONSTANT = 0, PYR_PROGRAM_INSTRUCTIONS = 1 } PyrProgramKind;

@@ -29,7 +29,7 @@ LAMP_DIRECTIONAL, LAMP_POINT, LAMP_SHAPE = 0, 1, 2
 SHAPE_SPHERE, SHAPE_TRIANGLE, SHAPE_PLANE = 0, 1, 2
 HIT_NONE = 0xFFFFFFFF
 
-MAX_NUMBER_REGISTERS, MAX_VECTOR_REGISTERS, MAX_RGB_REGISTERS = 16, 4, 4
+MAX_NUMBER_REGISTERS, MAX_VECTOR_REGISTERS, MAX_RGB_REGISTERS = 16, 8, 8
 
 
 class PyrGrain(C.Structure):

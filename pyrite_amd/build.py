@@ -28,7 +28,23 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+IMAGES_OUT = os.path.join(CSRC, "libpyrite_images.so")
+
+
+def build_images(force=False, verbose=False):
+    """Host-only texture ingest helper (baseline JPEG reader), plain C."""
+    src = os.path.join(CSRC, "jpeg.c")
+    if not force and os.path.exists(IMAGES_OUT) and os.path.getmtime(IMAGES_OUT) >= os.path.getmtime(src):
+        return IMAGES_OUT
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", "-o", IMAGES_OUT, src, "-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return IMAGES_OUT
+
+
 def build(force=False, extra_flags=(), verbose=False):
+    build_images(force, verbose)
     if not force and not stale():
         return OUT
     cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES

@@ -353,26 +353,26 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
         const PyrInstr& ins = S.instrs[p.first_instr + k];
         const uint32_t out = ins.output;
         switch (ins.op) {
-        case PYR_OP_NUMBER: num[out & 15] = __uint_as_float(ins.x.bits); break;
+        case PYR_OP_NUMBER: num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = __uint_as_float(ins.x.bits); break;
         case PYR_OP_VECTOR: {
             float x = value(ins.x), y = value(ins.y), z = value(ins.z), w = value(ins.w);
-            float* v = vec[out & 3];
+            float* v = vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
             v[0] = x, v[1] = y, v[2] = z, v[3] = w;
             break;
         }
         case PYR_OP_RGB: {
             float r = value(ins.x), g = value(ins.y), b = value(ins.z);
-            float* v = rgb[out & 3];
+            float* v = rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
             v[0] = r, v[1] = g, v[2] = b, v[3] = 1.0f;
             break;
         }
-        case PYR_OP_SPECTRUM: num[out & 15] = spectrum_get(S, ins.a, value(ins.x)); break;
+        case PYR_OP_SPECTRUM: num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = spectrum_get(S, ins.a, value(ins.x)); break;
         case PYR_OP_COLOR_TEXTURE: { // execution_context.rs:114-126
             float pos[4];
             vinput(ins.b, pos);
             float c[4];
             texture_get(S, ins.a, pos[0], pos[1], c);
-            float* v = rgb[out & 3];
+            float* v = rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
             for (int j = 0; j < 4; ++j) v[j] = c[j];
             break;
         }
@@ -381,12 +381,12 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
             vinput(ins.b, pos);
             float c[4];
             texture_get(S, ins.a, pos[0], pos[1], c);
-            num[out & 15] = c[0];
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = c[0];
             break;
         }
         case PYR_OP_RGB_SPECTRUM: {
             float wl = value(ins.x);
-            const float* c = rgb[ins.a & 3];
+            const float* c = rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
             float resp[3] = {0, 0, 0};
             uint32_t count = S.rgb_count;
             if (count > 0) {
@@ -404,7 +404,7 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
                     for (int j = 0; j < 3; ++j) resp[j] = d[3 * i0 + j] * (1.0f - mix) + d[3 * (i0 + 1) + j] * mix;
                 }
             }
-            num[out & 15] = c[0] * resp[0] + c[1] * resp[1] + c[2] * resp[2];
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = c[0] * resp[0] + c[1] * resp[1] + c[2] * resp[2];
             break;
         }
         case PYR_OP_FRESNEL: {
@@ -412,29 +412,29 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
             float nn[4], ii[4];
             vinput(ins.a, nn);
             vinput(ins.b, ii);
-            num[out & 15] = fresnel(ior, env, mk(nn[0], nn[1], nn[2]), mk(ii[0], ii[1], ii[2]));
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = fresnel(ior, env, mk(nn[0], nn[1], nn[2]), mk(ii[0], ii[1], ii[2]));
             break;
         }
         case PYR_OP_BLACKBODY: {
             float wl = value(ins.x), temp = value(ins.y);
-            num[out & 15] = blackbody(wl, temp);
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = blackbody(wl, temp);
             break;
         }
         case PYR_OP_RGB_TO_VECTOR: {
-            const float* c = rgb[ins.a & 3];
-            float* v = vec[out & 3];
+            const float* c = rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float* v = vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
             for (int j = 0; j < 4; ++j) v[j] = (c[j] * 2.0f) - 1.0f;
             break;
         }
         case PYR_OP_MIX: {
             float amount = fmaxf(fminf(value(ins.x), 1.0f), 0.0f);
             if (ins.value_type == PYR_VT_NUMBER) {
-                float l = num[ins.a & 15], r = num[ins.b & 15];
-                num[out & 15] = l * (1.0f - amount) + r * amount;
+                float l = num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], r = num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)];
+                num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = l * (1.0f - amount) + r * amount;
             } else {
-                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & 3] : rgb[ins.a & 3];
-                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & 3] : rgb[ins.b & 3];
-                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & 3] : rgb[out & 3];
+                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)];
+                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
                 float t[4];
                 for (int j = 0; j < 4; ++j) t[j] = l[j] + (r[j] - l[j]) * amount;
                 for (int j = 0; j < 4; ++j) o[j] = t[j];
@@ -443,11 +443,11 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
         }
         case PYR_OP_BINARY: {
             if (ins.value_type == PYR_VT_NUMBER) {
-                num[out & 15] = binop(ins.operator_, num[ins.a & 15], num[ins.b & 15]);
+                num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = binop(ins.operator_, num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)]);
             } else {
-                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & 3] : rgb[ins.a & 3];
-                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & 3] : rgb[ins.b & 3];
-                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & 3] : rgb[out & 3];
+                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)];
+                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
                 float t[4];
                 for (int j = 0; j < 4; ++j) t[j] = binop(ins.operator_, l[j], r[j]);
                 for (int j = 0; j < 4; ++j) o[j] = t[j];
@@ -456,20 +456,20 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
         }
         case PYR_OP_CLAMP: {
             float v = value(ins.x), mn = value(ins.y), mx = value(ins.z);
-            num[out & 15] = fmaxf(fminf(v, mx), mn);
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = fmaxf(fminf(v, mx), mn);
             break;
         }
         default: break;
         }
     }
     if (p.output_kind == PYR_OUTPUT_NUMBER) {
-        const float n = num[p.output_reg & 15];
+        const float n = num[p.output_reg & (PYR_MAX_NUMBER_REGISTERS - 1)];
         if (vector_out) vector_out[0] = vector_out[1] = vector_out[2] = vector_out[3] = n;
         return n;
     }
     if (vector_out)
-        for (int j = 0; j < 4; ++j) vector_out[j] = vec[p.output_reg & 3][j];
-    return vec[p.output_reg & 3][0];
+        for (int j = 0; j < 4; ++j) vector_out[j] = vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][j];
+    return vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][0];
 }
 
 // ExecutionContext::run (execution_context.rs:29-56) with the three shapes every Cornell-family program has short-cut.

@@ -3,14 +3,51 @@
 
 The reference decodes with the `image` crate and converts with `palette` 0.7.2; neither is vendored, so the conversions
 are restated from their published definitions: the sRGB transfer function (IEC 61966-2-1) for non-`linear` textures,
-`component / max` for linear ones and for alpha, Rec. 709 luma weights for colour -> mono. Only PNG is read here (the
-container has no image library); textures may also be handed over as arrays (see `compiler.FlatScene.texture_id`)."""
+`component / max` for linear ones and for alpha, Rec. 709 luma weights for colour -> mono. PNG is read in Python, baseline
+JPEG through the small native reader `csrc/jpeg.c` (libpyrite_images.so, built by `pyrite_amd.build`); the container has no
+image library. Textures may also be handed over as arrays (see `compiler.FlatScene.texture_id`)."""
+import ctypes as C
+import os
 import struct
 import zlib
 
 import numpy as np
 
 f32 = np.float32
+IMAGES_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpyrite_images.so")
+_images_lib = None
+
+
+def read_jpeg(path):
+    """-> uint8 array [height, width, 3] (grayscale files come back as three equal channels)."""
+    global _images_lib
+    if _images_lib is None:
+        if not os.path.exists(IMAGES_LIB):
+            raise OSError("%s is missing: run `python -m pyrite_amd.build`" % IMAGES_LIB)
+        lib = C.CDLL(IMAGES_LIB)
+        lib.pyr_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p,
+                                        C.c_size_t]
+        lib.pyr_image_free.argtypes = [C.POINTER(C.c_uint8)]
+        _images_lib = lib
+    with open(path, "rb") as f:
+        data = f.read()
+    w, h, rgb, err = C.c_int(), C.c_int(), C.POINTER(C.c_uint8)(), C.create_string_buffer(256)
+    if _images_lib.pyr_jpeg_decode(data, len(data), C.byref(w), C.byref(h), C.byref(rgb), err, len(err)) != 0:
+        raise ValueError("%s: %s" % (path, err.value.decode()))
+    try:
+        return np.ctypeslib.as_array(rgb, shape=(h.value, w.value, 3)).copy()
+    finally:
+        _images_lib.pyr_image_free(rgb)
+
+
+def read_image(path):
+    """The image formats project files use (image::ImageFormat::from_path, texture.rs:32-35): by extension."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".png":
+        return read_png(path)
+    if ext in (".jpg", ".jpeg"):
+        return read_jpeg(path)
+    raise ValueError("%s: unsupported image format (PNG and baseline JPEG are read)" % path)
 
 
 def read_png(path):
@@ -132,4 +169,4 @@ def linearise(image, linear, mono):
 
 
 def load_texture(path, linear, mono):
-    return linearise(read_png(path), linear, mono)
+    return linearise(read_image(path), linear, mono)

@@ -18,7 +18,7 @@ from types import SimpleNamespace
 
 __all__ = [
     "Expr", "Material", "Node", "vector", "rgb", "spectrum", "blackbody", "fresnel", "mix", "texture", "light_source",
-    "material", "shape", "light", "transform", "camera", "renderer", "bounds", "ray_marched",
+    "material", "shape", "light", "transform", "camera", "renderer", "bounds", "ray_marched", "quaternion_julia",
 ]
 
 
@@ -140,6 +140,8 @@ ray_marched = SimpleNamespace(  # lib.lua:220-231 -- accepted, rejected by the c
     quaternion_julia=lambda **props: Node("quaternion_julia", **props),
     mandelbulb=lambda **props: Node("mandelbulb", **props),
 )
+
+quaternion_julia = SimpleNamespace(cubic=Node("quaternion_julia", name="cubic"))  # lib.lua:228-230
 
 bounds = SimpleNamespace(box=lambda min, max: Node("box", min=min, max=max))  # lib.lua:237-243
 

@@ -205,9 +205,10 @@ def c3_flat(segments=640, sides=640, glass=False):
     return flat
 
 
-def build(project, seed=1):
+def build(project, seed=1, base_dir="."):
     """Project tree -> (World, Camera, Renderer, Film) through the same from_project constructors the reference uses
-    (main.rs:111-134 parse_project, :190-195 Film::new)."""
+    (main.rs:111-134 parse_project, :190-195 Film::new). Mesh and texture paths are relative to `base_dir`, the directory
+    of the project file (project/mod.rs:73-76)."""
     from .renderer import Camera, Renderer, World
 
     r = Renderer.from_project(project["renderer"], seed=seed)
@@ -215,8 +216,8 @@ def build(project, seed=1):
     if project.get("world") is None and "flat" in project:
         world = World(project["flat"]())
     else:
-        world = World.from_project(project["world"])
-    film = r.new_film(project["image"]["width"], project["image"]["height"])
+        world = World.from_project(project["world"], base_dir)
+    film = r.new_film(int(project["image"]["width"]), int(project["image"]["height"]))
     return world, cam, r, film
 
 

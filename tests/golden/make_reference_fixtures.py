@@ -30,18 +30,7 @@ def block_means(rgb8, block=BLOCK):
 
 
 def decode_jpeg(path):
-    """Baseline JPEG -> uint8 [h, w, 3] through tools/jpeg_decode.c (the container has no image library)."""
-    import subprocess
-    import tempfile
-
-    exe = os.path.join(tempfile.gettempdir(), "pyrite_jpeg_decode")
-    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "jpeg_decode.c"), "-lm"])
-    with tempfile.NamedTemporaryFile(suffix=".ppm") as tmp:
-        subprocess.check_call([exe, path, tmp.name])
-        raw = open(tmp.name, "rb").read()
-    header = raw.split(b"\n", 3)
-    w, h = (int(x) for x in header[1].split())
-    return np.frombuffer(header[3], dtype=np.uint8).reshape(h, w, 3)
+    return images.read_jpeg(path)
 
 
 def shrink(img, factor):
