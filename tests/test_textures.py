@@ -219,3 +219,49 @@ def test_textured_scene_renders_and_is_deterministic():
     assert c1 == c2 and np.array_equal(film.grains[..., 1], film2.grains[..., 1])
     assert np.isfinite(film.grains).all() and film.grains[..., 0].sum() > 0
     assert np.allclose(film.grains[..., 0], film2.grains[..., 0], rtol=1e-4, atol=1e-6)  # only the float-add order differs
+
+
+def _tiny_jpeg(levels, blocks_x):
+    """A baseline JPEG written by hand: one component, all-ones quantisation, flat 8 x 8 blocks (DC coefficients only), a
+    4-bit code for each of the 12 DC categories and a 1-bit end-of-block code."""
+    import struct
+
+    def segment(marker, body):
+        return b"\xff" + bytes([marker]) + struct.pack(">H", len(body) + 2) + body
+
+    blocks_y = len(levels) // blocks_x
+    out = b"\xff\xd8"
+    out += segment(0xDB, bytes([0]) + bytes([1] * 64))
+    out += segment(0xC0, struct.pack(">BHHB", 8, blocks_y * 8, blocks_x * 8, 1) + bytes([1, 0x11, 0]))
+    out += segment(0xC4, bytes([0x00]) + bytes([0, 0, 0, 12] + [0] * 12) + bytes(range(12)))  # DC: categories 0..11, 4 bits each
+    out += segment(0xC4, bytes([0x10]) + bytes([1] + [0] * 15) + bytes([0x00]))  # AC: only EOB, code "0"
+    out += segment(0xDA, bytes([1, 1, 0x00, 0, 63, 0]))
+    bits, pred = "", 0
+    for level in levels:
+        dc = 8 * (level - 128)  # F(0,0) of a flat block
+        diff, pred = dc - pred, dc
+        cat = abs(diff).bit_length()
+        bits += format(cat, "04b")
+        if cat:
+            bits += format(diff if diff > 0 else diff + (1 << cat) - 1, "0%db" % cat)
+        bits += "0"
+    bits += "1" * (-len(bits) % 8)
+    data = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)).replace(b"\xff", b"\xff\x00")
+    return out + data + b"\xff\xd9"
+
+
+def test_jpeg_reader_decodes_a_hand_written_baseline_file(tmp_path):
+    levels = [16, 128, 255, 0, 77, 200]
+    path = tmp_path / "flat.jpg"
+    path.write_bytes(_tiny_jpeg(levels, 3))
+    img = images.read_image(str(path))
+    assert img.shape == (16, 24, 3) and img.dtype == np.uint8
+    for k, level in enumerate(levels):
+        block = img[(k // 3) * 8:(k // 3) * 8 + 8, (k % 3) * 8:(k % 3) * 8 + 8]
+        assert np.all(block == level), (k, level, block[0, 0])
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"not a jpeg at all")
+    with pytest.raises(ValueError, match="not a JPEG"):
+        images.read_image(str(bad))
+    with pytest.raises(ValueError, match="unsupported image format"):
+        images.read_image(str(tmp_path / "x.tiff"))
