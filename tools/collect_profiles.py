@@ -34,14 +34,19 @@ def counter_sum(path, counter, kernel_part):
 
 
 copy("c2_trace/c2_kernel_stats.csv", "c2_kernel_stats.csv")
+if os.path.exists(os.path.join(SRC, "c3_trace", "c3_kernel_stats.csv")):
+    copy("c3_trace/c3_kernel_stats.csv", "c3_kernel_stats.csv")
 copy("isect_trace/isect_kernel_stats.csv", "intersect_kernel_stats.csv")
 # keep only our kernels' rows of the (large) kernel trace
 with open(os.path.join(SRC, "c2_trace", "c2_kernel_trace.csv")) as f, open(os.path.join(DST, tag + "_c2_kernel_trace_render.csv"), "w") as g:
     for i, line in enumerate(f):
         if i == 0 or "pyr::" in line:
             g.write(line)
-for name in ("c2_fetch/fetch_counter_collection.csv", "c2_write/write_counter_collection.csv"):
-    out = os.path.join(DST, "%s_c2_pmc_%s.csv" % (tag, "fetch_size" if "fetch" in name else "write_size"))
+pmc_files = ["c2_fetch/fetch_counter_collection.csv", "c2_write/write_counter_collection.csv"]
+if os.path.exists(os.path.join(SRC, "c3_fetch", "fetch_counter_collection.csv")):
+    pmc_files += ["c3_fetch/fetch_counter_collection.csv", "c3_write/write_counter_collection.csv"]
+for name in pmc_files:
+    out = os.path.join(DST, "%s_%s_pmc_%s.csv" % (tag, name[:2], "fetch_size" if "fetch" in name else "write_size"))
     with open(os.path.join(SRC, name)) as f, open(out, "w") as g:
         for i, line in enumerate(f):
             if i == 0 or "pyr::" in line:
@@ -66,6 +71,19 @@ traffic = {
         "note": "all of it is the film: two no-return f32 atomics per exposure, 32 B each at the memory side; the 2.8 KB scene is read from LDS",
     }
 }
+if os.path.exists(os.path.join(SRC, "c3_fetch", "fetch_counter_collection.csv")):
+    fetch = counter_sum(os.path.join(SRC, "c3_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", "render_kernel_sm<false")
+    write = counter_sum(os.path.join(SRC, "c3_write", "write_counter_collection.csv"), "WRITE_SIZE", "render_kernel_sm<false")
+    (kernel3, fv), = fetch.items()
+    (_, wv), = write.items()
+    f3, w3 = sum(fv) / len(fv), sum(wv) / len(wv)
+    traffic["C3"] = {
+        "hbm_bytes_per_launch": int((2.0 * f3 + w3) * 1024.0),
+        "source": "rocprofv3 --pmc FETCH_SIZE (%.1f KB) and --pmc WRITE_SIZE (%.1f KB) in separate passes on `bench.py --workload C3 --steps 1 --warmup 0`, %s, %s"
+                  % (f3, w3, kernel3.replace("void ", ""), datetime.date.today().isoformat()),
+        "formula": traffic["C2"]["formula"],
+        "note": "reads: BVH nodes / primitives / shading records that missed L2 (the 56 MB tree sits in the 256 MB Infinity Cache, whose hits the counter still includes); writes: the film's f32 atomics",
+    }
 with open(os.path.join(DST, "traffic.json"), "w") as g:
     json.dump(traffic, g, indent=1)
     g.write("\n")
