@@ -294,6 +294,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world_size > 1:
+        dist.barrier()  # rank 0 ran the instrumented pass above: leave together
         dist.destroy_process_group()
 
 
