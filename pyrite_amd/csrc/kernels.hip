@@ -4,11 +4,19 @@
 // calls: sample generation, tracer::trace (tracer.rs:208-345), trace_direct (:347-442), the spectral fold `contribute`
 // (renderer/algorithm.rs:14-100, applied online bounce by bounce) and Film::expose (film.rs:89-95).
 //
-// Execution model (DESIGN.md "Kernel"): one persistent launch; a wave walks a strided sequence of 64-iteration chunks
-// and every LANE owns one sample at a time and refills itself as soon as its path ends (no lane waits for the wave's
-// longest path). Per lane: path state in VGPRs, the S spectral companions (wavelength / brightness / reflectance) and
-// the traversal stack in LDS laid out [entry][lane] (bank-conflict free), BVH nodes fetched as 4 x dwordx4 (64 B, both
-// children's boxes), leaf primitives as 3 x dwordx4. Film exposure is two no-return global_atomic_add_f32 per exposure.
+// Execution models, all running the same per-path code and so producing the same film:
+//   render_kernel      one persistent launch; a wave walks a strided sequence of 64-iteration chunks, lane = iteration, and
+//                      the 64 paths advance bounce by bounce (scenes that fit in LDS: C1, C2)
+//   render_kernel_sm   every lane runs its path as a state machine (Walker) and refills itself; the wave votes on which
+//                      phase code runs next; traversal is resumable (big scenes: C3-C5, textured scenes)
+//   wf_logic_kernel +  the same state machine split at the ray, path state in a pool in HBM (optional)
+//   wf_trav_kernel
+//   intersect_kernel   World::intersect for ray batches: persistent waves with a segmented work feed
+//   develop_kernel     film -> 8-bit sRGB
+// Per lane: path state in VGPRs, the S - 1 spectral companions (wavelength / brightness / reflectance) and the traversal
+// stack in LDS laid out [entry][lane] (bank-conflict free), BVH nodes fetched as 4 x dwordx4 (64 B, both children's boxes,
+// tested with packed fp32), leaf primitives as 3 x dwordx4, one primitive per step. Film exposure is two no-return
+// global_atomic_add_f32 per exposure.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
