@@ -114,6 +114,20 @@ def test_vertical_image_single_wavelength_and_no_light_samples(gpu_lib):
     assert gfilm.total_weight() == 24 * 40 * 4
 
 
+@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
+def test_world_without_objects_is_all_sky(scheduler, gpu_lib, monkeypatch):
+    """No primitives at all (the BVH is a root with two empty leaves): every path misses and shows the sky."""
+    from pyrite_amd.project import light_source
+
+    monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
+    project = scenes.lamps_example(40, 24, 4)
+    project["world"] = {"sky": light_source.d65 * 0.5, "objects": []}
+    gfilm, cfilm, gcount, ccount = render_both(project, 3, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    assert gcount["shaded_hits"] == 0 and gcount["extension_rays"] == gcount["samples"] == 40 * 24 * 4 and gcount == {**ccount, "box_tests": gcount["box_tests"]}
+    assert gfilm.grains[..., 0].sum() > 0
+
+
 def test_empty_work_is_a_no_op(gpu_lib):
     world, cam, r, film = scenes.build(scenes.c2_cornell(16, 16, 0), seed=1)  # zero samples per pixel
     r.render(film, cam, world)
