@@ -207,8 +207,10 @@ def main():
     t0 = time.perf_counter()
     start_evt.record(stream)
     film = None
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        renderer.seed = args.seed + k % 3  # seeds 1, 2, 3 in turn; a step is one full render either way
         film = step()
+    renderer.seed = args.seed
     stop_evt.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
@@ -238,6 +240,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "seeds": sorted({args.seed + k % 3 for k in range(args.steps)}),
             "config": {
                 "workload": "%s: %s, %dx%d, %d spp%s" % (args.workload, builder, width, height, spp, " (REDUCED spp: development run)" if reduced else ""),
                 "bounces": renderer.bounces, "light_samples": renderer.light_samples, "spectrum_samples": renderer.spectrum_samples,
