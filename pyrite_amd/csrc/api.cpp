@@ -190,7 +190,7 @@ struct PyrScene {
     int num_cus = 0;
     DevScene dev{};
     PyrBvhInfo info{};
-    DeviceBuffer nodes, prims, tri_shade, spheres, sphere_material, planes, plane_material, lamps, materials, components, programs, instrs, spectra,
+    DeviceBuffer wide_nodes, nodes, prims, tri_shade, spheres, sphere_material, planes, plane_material, lamps, materials, components, programs, instrs, spectra,
         spectrum_data, rgb_basis, counters, tri_tex, sphere_tex_scale, plane_frames, textures, texture_data;
     PyrCounters last_counters{};
     bool have_counters = false;
@@ -410,6 +410,16 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     if ((rc = s->textures.upload(textures.data(), textures.size() * sizeof(DevTexture)))) return rc;
     if ((rc = s->texture_data.upload(d->texture_data, d->num_textures ? (size_t)d->num_texture_floats * 4 : 0))) return rc;
     if ((rc = s->nodes.upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64)))) return rc;
+    // scenes that do not live in LDS also get the 4-wide tree for the resumable traversal (latency bound there);
+    // PYRITE_WIDE_BVH=0 keeps the binary tree (A/B)
+    WideBvh wide;
+    const char* wide_env = std::getenv("PYRITE_WIDE_BVH");
+    const bool want_wide = (size_t)bvh.nodes.size() * 64 + prims.size() * 48 > 8 * 1024 && !(wide_env && wide_env[0] == '0');
+    if (want_wide) {
+        wide = collapse_to_wide(bvh);
+        if (wide.stack_need > kMaxStackDepth) wide = WideBvh{};
+    }
+    if ((rc = s->wide_nodes.upload(wide.nodes.data(), wide.nodes.size() * sizeof(Node128)))) return rc;
     if ((rc = s->prims.upload(prims.data(), prims.size() * sizeof(DevPrim)))) return rc;
     if ((rc = s->tri_shade.upload(shade.data(), shade.size() * sizeof(DevTriShade)))) return rc;
     if ((rc = s->spheres.upload(d->spheres, (size_t)d->num_spheres * 16))) return rc;
@@ -428,6 +438,8 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
 
     DevScene& v = s->dev;
     v.nodes = (const float*)s->nodes.ptr;
+    v.wide_nodes = wide.nodes.empty() ? nullptr : (const float*)s->wide_nodes.ptr;
+    v.wide_stack_depth = std::max(1u, wide.stack_need);
     v.prims = (const float*)s->prims.ptr;
     v.tri_shade = (const float*)s->tri_shade.ptr;
     v.spheres = (const float*)s->spheres.ptr;

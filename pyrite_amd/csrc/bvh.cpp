@@ -221,4 +221,73 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
     return out;
 }
 
+WideBvh collapse_to_wide(const BuiltBvh& bvh) {
+    WideBvh out;
+    struct Child {
+        float lo[3], hi[3];
+        int32_t code; // Node64 child code
+    };
+    auto child_of = [&](const Node64& n, int k) {
+        Child c;
+        c.lo[0] = n.lo_x[k], c.lo[1] = n.lo_y[k], c.lo[2] = n.lo_z[k];
+        c.hi[0] = n.hi_x[k], c.hi[1] = n.hi_y[k], c.hi[2] = n.hi_z[k];
+        c.code = n.child[k];
+        return c;
+    };
+    auto area = [](const Child& c) {
+        float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+        return (dx > 0 && dy >= 0 && dz >= 0) || (dy > 0 && dx >= 0 && dz >= 0) || (dz > 0 && dx >= 0 && dy >= 0) ? dx * dy + dy * dz + dz * dx : 0.0f;
+    };
+    struct Task {
+        int32_t binary_node; // Node64 index this wide node stands for
+        int32_t wide_index;
+        uint32_t depth, stack_before;
+    };
+    out.nodes.emplace_back();
+    std::vector<Task> todo{{0, 0, 1, 0}};
+    while (!todo.empty()) {
+        Task t = todo.back();
+        todo.pop_back();
+        std::vector<Child> kids{child_of(bvh.nodes[t.binary_node], 0), child_of(bvh.nodes[t.binary_node], 1)};
+        for (;;) {
+            if (kids.size() >= 4) break;
+            int best = -1;
+            float best_area = -1.0f;
+            for (size_t i = 0; i < kids.size(); ++i)
+                if (kids[i].code >= 0 && area(kids[i]) > best_area) best_area = area(kids[i]), best = (int)i;
+            if (best < 0) break;
+            const Node64& inner = bvh.nodes[kids[best].code];
+            kids[best] = child_of(inner, 0);
+            kids.push_back(child_of(inner, 1));
+        }
+        // drop empty leaves (a binary node with fewer than two real children)
+        std::vector<Child> real;
+        for (const Child& c : kids)
+            if (c.code >= 0 || ((uint32_t)(-1 - c.code) & 7u) != 0) real.push_back(c);
+        Node128 node{};
+        for (int k = 0; k < 4; ++k) {
+            node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = kInf;
+            node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = -kInf;
+            node.child[k] = kEmptyChild;
+        }
+        const uint32_t pushes = real.empty() ? 0u : (uint32_t)real.size() - 1u;
+        out.max_depth = std::max(out.max_depth, t.depth);
+        out.stack_need = std::max(out.stack_need, t.stack_before + pushes);
+        for (size_t k = 0; k < real.size(); ++k) {
+            node.lo_x[k] = real[k].lo[0], node.lo_y[k] = real[k].lo[1], node.lo_z[k] = real[k].lo[2];
+            node.hi_x[k] = real[k].hi[0], node.hi_y[k] = real[k].hi[1], node.hi_z[k] = real[k].hi[2];
+            if (real[k].code >= 0) {
+                const int32_t index = (int32_t)out.nodes.size();
+                out.nodes.emplace_back();
+                node.child[k] = index;
+                todo.push_back(Task{real[k].code, index, t.depth + 1, t.stack_before + pushes});
+            } else {
+                node.child[k] = real[k].code;
+            }
+        }
+        out.nodes[t.wide_index] = node;
+    }
+    return out;
+}
+
 } // namespace pyr

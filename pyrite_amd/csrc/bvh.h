@@ -9,6 +9,7 @@
 // Closest-hit results do not depend on the tree (only exact-distance ties do).
 #pragma once
 #include <cstdint>
+#include <climits>
 #include <vector>
 
 namespace pyr {
@@ -47,5 +48,24 @@ constexpr uint32_t kMaxBvhDepth = 40;
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return -1 - (int32_t)((first << 3) | count); }
 
 BuiltBvh build_bvh(const std::vector<PrimBounds>& prims);
+
+// Four-child node, 128 bytes = one L2 line, read as eight float4: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4]
+// pad[4]. Built by collapsing the binary tree (the child with the largest surface area is replaced by its own two children
+// until the node has four): a ray then makes about half as many dependent node fetches. Used by the resumable traversal
+// on scenes that do not live in LDS, where the walk is latency bound; unused slots hold kEmptyChild and are never entered.
+struct alignas(128) Node128 {
+    float lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4];
+    int32_t child[4]; // >= 0: Node128 index; < 0: leaf code as in Node64; kEmptyChild: nothing
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node128) == 128, "wide node must be 128 bytes");
+constexpr int32_t kEmptyChild = INT32_MIN;
+
+struct WideBvh {
+    std::vector<Node128> nodes; // nodes[0] is the root
+    uint32_t max_depth = 0;     // node levels on the longest path
+    uint32_t stack_need = 0;    // entries an ordered traversal can hold at once: max over paths of sum(children - 1)
+};
+WideBvh collapse_to_wide(const BuiltBvh& bvh);
 
 } // namespace pyr

@@ -65,6 +65,8 @@ struct DevProgram {
 
 struct DevScene {
     const float* nodes;  // Node64[], 16 floats each
+    const float* wide_nodes; // Node128[], 32 floats each, or nullptr: the tree the resumable traversal walks on big scenes
+    uint32_t wide_stack_depth; // stack entries that tree can need
     const float* prims;  // DevPrim[], 12 floats each
     const float* tri_shade; // DevTriShade[]
     const float* spheres;   // [n][4] centre, radius (original order)
@@ -97,7 +99,7 @@ struct DevScene {
     uint32_t uses_textures; // some program holds a texture opcode or some material a normal map
 };
 
-constexpr uint32_t kMaxStackDepth = 40; // >= kMaxBvhDepth (bvh.h): the deepest tree build_bvh produces
+constexpr uint32_t kMaxStackDepth = 64; // >= kMaxBvhDepth (bvh.h) and >= the wide tree's stack need (else the binary tree is walked)
 
 // Everything one render launch needs besides the scene.
 struct RenderLaunch {

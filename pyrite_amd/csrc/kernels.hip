@@ -1152,10 +1152,15 @@ struct Path {
 struct SceneView {
     const float4* nodes;
     const float4* prims;
+    bool wide = false; // nodes are Node128 (four children); only the resumable traversal walks those
 };
 template <bool LDS_SCENE>
-DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_before) {
+DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_before, bool resumable = false) {
     SceneView v{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
+    if (!LDS_SCENE && resumable && S.wide_nodes != nullptr) {
+        v.nodes = reinterpret_cast<const float4*>(S.wide_nodes);
+        v.wide = true;
+    }
     if constexpr (LDS_SCENE) {
         float4* staged = reinterpret_cast<float4*>(lds + lds_floats_before);
         const uint32_t node_vecs = S.num_nodes * 4, prim_vecs = S.num_prims * 3;
@@ -1654,8 +1659,66 @@ struct TravStack {
 };
 
 // One node visit or one leaf. Returns true when the traversal has finished. Same tests, same order as traverse<>.
+// One visit of a four-child node (bvh.h Node128). The twelve plane distances of two children at a time are v_pk_fma_f32;
+// the children that are hit are ordered by entry distance with a five-comparator network, the nearest is entered and the
+// others are pushed far to near, so they pop nearest first. Returns true when the traversal has finished.
+template <bool COUNT>
+DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
+    const float4* nd = view.nodes + 8 * (size_t)t.node;
+    const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5], ch = nd[6];
+    const f2v ix = {t.inv.x, t.inv.x}, iy = {t.inv.y, t.inv.y}, iz = {t.inv.z, t.inv.z};
+    const float ox = -(t.o.x * t.inv.x), oy = -(t.o.y * t.inv.y), oz = -(t.o.z * t.inv.z);
+    const f2v nox = {ox, ox}, noy = {oy, oy}, noz = {oz, oz};
+    float e[4];
+    int c[4] = {__float_as_int(ch.x), __float_as_int(ch.y), __float_as_int(ch.z), __float_as_int(ch.w)};
+    {
+        const f2v alx = __builtin_elementwise_fma((f2v){lx.x, lx.y}, ix, nox), ahx = __builtin_elementwise_fma((f2v){hx.x, hx.y}, ix, nox);
+        const f2v aly = __builtin_elementwise_fma((f2v){ly.x, ly.y}, iy, noy), ahy = __builtin_elementwise_fma((f2v){hy.x, hy.y}, iy, noy);
+        const f2v alz = __builtin_elementwise_fma((f2v){lz.x, lz.y}, iz, noz), ahz = __builtin_elementwise_fma((f2v){hz.x, hz.y}, iz, noz);
+        const f2v blx = __builtin_elementwise_fma((f2v){lx.z, lx.w}, ix, nox), bhx = __builtin_elementwise_fma((f2v){hx.z, hx.w}, ix, nox);
+        const f2v bly = __builtin_elementwise_fma((f2v){ly.z, ly.w}, iy, noy), bhy = __builtin_elementwise_fma((f2v){hy.z, hy.w}, iy, noy);
+        const f2v blz = __builtin_elementwise_fma((f2v){lz.z, lz.w}, iz, noz), bhz = __builtin_elementwise_fma((f2v){hz.z, hz.w}, iz, noz);
+        const float tl[4][3] = {{alx.x, aly.x, alz.x}, {alx.y, aly.y, alz.y}, {blx.x, bly.x, blz.x}, {blx.y, bly.y, blz.y}};
+        const float th[4][3] = {{ahx.x, ahy.x, ahz.x}, {ahx.y, ahy.y, ahz.y}, {bhx.x, bhy.x, bhz.x}, {bhx.y, bhy.y, bhz.y}};
+        for (int k = 0; k < 4; ++k) {
+            const float tmin = fmaxf(fmaxf(fminf(tl[k][0], th[k][0]), fminf(tl[k][1], th[k][1])), fminf(tl[k][2], th[k][2]));
+            const float tmax = fminf(fminf(fmaxf(tl[k][0], th[k][0]), fmaxf(tl[k][1], th[k][1])), fmaxf(tl[k][2], th[k][2]));
+            const float entry = fmaxf(tmin, 0.0f);
+            bool hit = tmax >= tmin && tmax >= 0.0f && c[k] != INT32_MIN;
+            if (COUNT) cnt.box_tests += c[k] != INT32_MIN ? 1u : 0u;
+            hit = hit && (t.shadow ? entry * entry < t.limit_cull : entry < t.closest);
+            e[k] = hit ? entry : PYR_INF; // misses sort last
+            if (!hit) c[k] = INT32_MIN;
+        }
+    }
+    // order (e, c) ascending: network (0,1) (2,3) (0,2) (1,3) (1,2)
+    auto order = [&](int a, int b) {
+        const bool sw = e[b] < e[a];
+        const float ea = sw ? e[b] : e[a], eb = sw ? e[a] : e[b];
+        const int ca = sw ? c[b] : c[a], cb = sw ? c[a] : c[b];
+        e[a] = ea, e[b] = eb, c[a] = ca, c[b] = cb;
+    };
+    order(0, 1);
+    order(2, 3);
+    order(0, 2);
+    order(1, 3);
+    order(1, 2);
+    if (c[0] == INT32_MIN) { // nothing hit
+        if (t.sp == 0) return true;
+        t.sp--;
+        t.node = stack.pop(t.sp);
+        return false;
+    }
+    if (c[3] != INT32_MIN) stack.push(t.sp++, c[3]);
+    if (c[2] != INT32_MIN) stack.push(t.sp++, c[2]);
+    if (c[1] != INT32_MIN) stack.push(t.sp++, c[1]);
+    t.node = c[0];
+    return false;
+}
+
 template <bool COUNT>
 DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
+    if (t.node >= 0 && view.wide) return trav_step_wide<COUNT>(view, t, stack, cnt);
     if (t.node >= 0) {
         const float4* nd = view.nodes + 4 * t.node;
         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
@@ -2018,7 +2081,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
     const uint32_t lds_base_floats = (3 * SS + L.stack_lds) * BLOCK;
-    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
+    const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats, true);
     const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -2111,7 +2174,8 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
     stack.lds = lds_stack + threadIdx.x;
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
-    const SceneView view{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
+    const SceneView view = S.wide_nodes ? SceneView{reinterpret_cast<const float4*>(S.wide_nodes), reinterpret_cast<const float4*>(S.prims), true}
+                                        : SceneView{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), false};
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
     bool busy = false;
@@ -2335,7 +2399,8 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
     stack.lds = lds_stack + threadIdx.x;
     stack.lds_entries = (int)stack_lds;
     Counters cnt{};
-    const SceneView view{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
+    const SceneView view = S.wide_nodes ? SceneView{reinterpret_cast<const float4*>(S.wide_nodes), reinterpret_cast<const float4*>(S.prims), true}
+                                        : SceneView{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), false};
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
     const size_t n = P.n;
@@ -2493,7 +2558,7 @@ static uint32_t short_stack_levels(const DevScene& scene, size_t other_bytes, ui
         levels = budget > other_bytes ? (uint32_t)((budget - other_bytes) / (BLOCK * sizeof(int))) : 0u;
         levels = std::min(levels, kShortStackMax);
     }
-    return std::max(1u, std::min(levels, scene.stack_depth));
+    return std::max(1u, std::min(levels, scene.wide_nodes ? scene.wide_stack_depth : scene.stack_depth));
 }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     size_t bytes = (size_t)(3 * launch.spectrum_samples + launch.stack_lds) * BLOCK * sizeof(float);

@@ -169,6 +169,30 @@ def test_closest_hit_on_a_dense_mesh(gpu_lib):
     assert (ohits["shape"] != 0xFFFFFFFF).mean() > 0.1
 
 
+def test_wide_and_binary_trees_answer_alike(gpu_lib, monkeypatch):
+    """Scenes that do not live in LDS are walked through the 4-wide collapse of the binary tree (bvh.h Node128);
+    PYRITE_WIDE_BVH=0 keeps the binary tree. Same hits, same film, fewer box tests."""
+    from pyrite_amd.renderer import Camera, Renderer, World
+
+    project = scenes.c3_mesh_in_box(width=48, height=27, pixel_samples=4)
+    rays = random_rays(50000, 12, [-55, 0, 0], [0, 55, 54])
+    results = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("PYRITE_WIDE_BVH", wide)
+        world = World(scenes.c3_flat(segments=96, sides=48))
+        hits, _, counters = world.intersect(rays, want_counters=True)
+        r = Renderer.from_project(project["renderer"], seed=2)
+        film = r.new_film(48, 27)
+        r.render(film, Camera.from_project(project["camera"]), world)
+        results[wide] = (hits, counters, film)
+    (h1, c1, f1), (h0, c0, f0) = results["1"], results["0"]
+    assert_same_hits(h0, h1)
+    assert c1["triangle_tests"] <= 1.1 * c0["triangle_tests"] and c1["box_tests"] < c0["box_tests"]
+    assert_parity(f1, f0)
+    ohits, _ = oracle.OracleScene(world).intersect(rays)
+    assert_same_hits(ohits, h1)
+
+
 @pytest.mark.parametrize("glass", [False, True])
 def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
     """C3 / C5 in small: the x10 Cornell box with a (coarser) torus-knot mesh, diffuse or dispersive glass. At this scale
