@@ -2093,30 +2093,41 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
 
     PROF_DECL;
     for (;;) {
-        const int nT = __popcll(__ballot(w.stage == ST_TRAV));
-        const int nS = __popcll(__ballot(w.stage == ST_SHADE));
-        const int nN = __popcll(__ballot(w.stage == ST_NEE));
-        const int nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
-        const int best = max(max(nT, nS), max(nN, nE));
-        if (best == 0) break; // every lane is DONE
+        // every decision looks at the lanes as they are now: a lane that has just been shaded and starts its next-event
+        // estimation is counted for the NEE phase of this same turn, one that has just drawn a shadow ray for the traversal
+        int nT = __popcll(__ballot(w.stage == ST_TRAV));
+        int nS = __popcll(__ballot(w.stage == ST_SHADE));
+        int nN = __popcll(__ballot(w.stage == ST_NEE));
+        int nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+        if (max(max(nT, nS), max(nN, nE)) == 0) break; // every lane is DONE
 
-        if (nE >= phase_lanes || nE == best) {
+        if (nE >= phase_lanes || nE == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             w.expose_and_restart(S, L, spec, cnt, lane, total_waves);
             PROF_END(0);
+            nT = __popcll(__ballot(w.stage == ST_TRAV));
+            nS = __popcll(__ballot(w.stage == ST_SHADE));
+            nE = 0;
         }
-        if (nS >= phase_lanes || nS == best) {
+        if (nS >= phase_lanes || nS == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(1, w.stage == ST_SHADE);
             w.shade(S, L, spec, cnt);
             PROF_END(1);
+            nT = __popcll(__ballot(w.stage == ST_TRAV));
+            nN = __popcll(__ballot(w.stage == ST_NEE));
+            nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+            nS = 0;
         }
-        if (nN >= phase_lanes || nN == best) {
+        if (nN >= phase_lanes || nN == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(2, w.stage == ST_NEE);
             w.next_event(S, L, spec, cnt);
             PROF_END(2);
+            nT = __popcll(__ballot(w.stage == ST_TRAV));
+            nN = __popcll(__ballot(w.stage == ST_NEE));
+            nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
         }
         // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
-        if (nT >= phase_lanes || nT == best) {
+        if (nT >= phase_lanes || nT == max(max(nT, nS), max(nN, nE))) {
 #ifdef PYR_PHASE_PROFILE
             const unsigned long long prof_t0_3 = clock64();
 #endif
