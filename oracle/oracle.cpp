@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -1792,6 +1793,21 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
             contribute(bounce, main_sample, additional_samples.data(), use_additional ? additional_samples.size() : 0, exe);
         }
 
+        if (const char* dbg = std::getenv("ORACLE_DEBUG_PIXEL")) { // developer aid: ORACLE_DEBUG_PIXEL=x,y prints the samples of one pixel
+            unsigned dx = 0, dy = 0;
+            uint64_t qx, qy;
+            if (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy) {
+                std::fprintf(stderr, "[oracle] tile %u iteration %llu hero %.3f nm brightness %.9g use_additional %d bounces %zu\n", tile.raster_index,
+                             (unsigned long long)i, main_sample.wavelength, main_sample.brightness, (int)use_additional, path.size());
+                for (const Bounce& b : path) {
+                    std::fprintf(stderr, "    bounce type %d color %u prob %.9g dispersed %d pos (%.9g %.9g %.9g) normal (%.6f %.6f %.6f) out (%.6f %.6f %.6f) lights %zu:", (int)b.ty,
+                                 b.color, b.probability, (int)b.dispersed, b.position.x, b.position.y, b.position.z, b.normal.x, b.normal.y, b.normal.z, b.out.x, b.out.y,
+                                 b.out.z, b.direct_light.size());
+                    for (const DirectLight& dl : b.direct_light) std::fprintf(stderr, " [color %u prob %.9g dir (%.9g %.9g %.9g)]", dl.color, dl.probability, dl.incident.x, dl.incident.y, dl.incident.z);
+                    std::fprintf(stderr, "\n");
+                }
+            }
+        }
         film_expose(film, px, py, main_sample.wavelength, main_sample.brightness, main_sample.weight, c);
         if (use_additional)
             for (const SpectralSample& sm : additional_samples) film_expose(film, px, py, sm.wavelength, sm.brightness, sm.weight, c);

@@ -664,6 +664,19 @@ DEV float slab(f3 lo, f3 hi, f3 o, f3 inv) {
     return (tmax >= tmin && tmax >= 0.0f) ? fmaxf(tmin, 0.0f) : -1.0f;
 }
 
+// The reference never calls a shape's intersection routine unless the ray passes the shape's own bounding box
+// (spatial/bvh.rs:201-230: one item per leaf; math.rs:184-207 for the box) and enters it before the closest hit so far. For
+// triangles that changes nothing but ties at the box surface; collision's sphere routine, however, assumes a unit direction
+// (`tca = l . d`, `d2 = l . l - tca^2`) and reports hits for rays that pass the sphere at a distance when the direction is
+// longer than 1 -- a directional lamp whose `direction` is not normalised produces such rays (lamp.rs:24-35) -- and the
+// reference is only saved from them by that box. Leaves here hold up to four primitives under one box, so spheres get the
+// reference's own test, in its own arithmetic (IEEE 1 / d, (bound - o) * inv), before the sphere routine runs.
+DEV bool sphere_box_guard(f3 center, float radius, f3 o, f3 d, float closest, bool any_hit) {
+    const f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float entry = slab(mk(center.x - radius, center.y - radius, center.z - radius), mk(center.x + radius, center.y + radius, center.z + radius), o, inv);
+    return entry >= 0.0f && (any_hit || entry < closest);
+}
+
 // Both children of a node at once. The node stores the bounds interleaved (bvh.h Node64: q0 = lo.x lo.y, q1 = lo.z hi.x,
 // q2 = hi.y hi.z, each as a (child 0, child 1) pair), so the twelve plane distances are six v_pk_fma_f32:
 // t = bound * inv - o * inv. That form rounds differently from math.rs:184-207's (bound - o) * inv; the boxes are this
@@ -771,7 +784,7 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
             } else {
                 f3 point;
                 if (COUNT) cnt.sphere_tests++;
-                ok = sphere_test(mk(a.x, a.y, a.z), b.x, o, d, dist, point);
+                ok = sphere_box_guard(mk(a.x, a.y, a.z), b.x, o, d, closest, SHADOW) && sphere_test(mk(a.x, a.y, a.z), b.x, o, d, dist, point);
             }
             if (ok) {
                 if (SHADOW) {
@@ -1767,7 +1780,7 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
         } else {
             f3 point;
             if (COUNT) cnt.sphere_tests++;
-            ok = sphere_test(mk(a.x, a.y, a.z), b.x, t.o, t.d, dist, point);
+            ok = sphere_box_guard(mk(a.x, a.y, a.z), b.x, t.o, t.d, t.closest, t.shadow) && sphere_test(mk(a.x, a.y, a.z), b.x, t.o, t.d, dist, point);
         }
         if (ok) {
             if (t.shadow) {

@@ -1,0 +1,140 @@
+"""Seeded random scenes -- mixed primitives, every material kind and lamp kind, textures and normal maps, odd renderer
+parameters -- rendered by every scheduler and compared with the oracle sample for sample. The hand-written scenes cover what
+the reference's projects do; this covers combinations nobody thought of."""
+import numpy as np
+import pytest
+
+import oracle
+from pyrite_amd import scenes
+from pyrite_amd.project import (blackbody, camera, fresnel, light, light_source, material, mix, renderer, rgb, shape, spectrum, texture, transform,
+                                vector)
+from test_gpu_parity import rel_l2
+
+f32 = np.float32
+
+
+def assert_parity(gpu_film, cpu_film):
+    """As test_gpu_parity.assert_parity, for images of a few hundred pixels: the two sides add the same exposures to a grain
+    in different orders (float atomics), and a pixel that sums values of very different size can differ by more than 1e-5
+    relative; allow two such pixels (or 0.2 %), none beyond 1e-3."""
+    assert np.array_equal(gpu_film.grains[..., 1], cpu_film.grains[..., 1]), "film weights differ"
+    e = rel_l2(gpu_film, cpu_film)
+    assert (e > 1e-5).sum() <= max(2, 0.002 * e.size) and e.max() <= 1e-3, "relL2: %d of %d pixels above 1e-5, max %.3g" % ((e > 1e-5).sum(), e.size, e.max())
+    assert not np.isnan(gpu_film.grains).any()
+
+
+def random_project(seed):
+    rng = np.random.default_rng(seed)
+    tex = scenes._generated_textures(seed=seed, size=8)
+
+    def colour():
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            return float(rng.uniform(0.2, 0.95))
+        if kind == 1:
+            pts = np.sort(rng.uniform(390, 760, 4))
+            return spectrum(format="curve", points=[[float(pts[0]), 0.0], [float(pts[1]), float(rng.uniform(0.3, 1))], [float(pts[2]), float(rng.uniform(0.3, 1))], [float(pts[3]), 0.0]])
+        if kind == 2:
+            return spectrum(format="array", min=400.0, max=700.0, points=[float(x) for x in rng.uniform(0.1, 0.9, 7)])
+        if kind == 3:
+            return rgb(*[float(x) for x in rng.uniform(0.05, 0.95, 3)])
+        if kind == 4:
+            return texture(tex["checker"]) * float(rng.uniform(0.5, 1.0))
+        return mix(float(rng.uniform(0.1, 0.4)), float(rng.uniform(0.6, 0.9)), fresnel(float(rng.uniform(1.1, 1.8))))
+
+    def surface(depth=0):
+        kind = rng.integers(0, 7 if depth < 2 else 4)
+        if kind == 0:
+            return material.diffuse(color=colour())
+        if kind == 1:
+            return material.mirror(color=colour())
+        if kind == 2:
+            disp = float(rng.uniform(0.005, 0.02)) if rng.random() < 0.5 else None
+            return material.refractive(ior=float(rng.uniform(1.2, 2.4)), color=colour(), dispersion=disp)
+        if kind == 3:
+            return material.diffuse(color=colour())
+        if kind == 4:
+            amount = [float(rng.uniform(0.2, 0.8)), fresnel(float(rng.uniform(1.2, 1.7))), texture(tex["mono"], "mono", "linear")][rng.integers(0, 3)]
+            return mix(surface(depth + 1), surface(depth + 1), amount)
+        if kind == 5:
+            return material.emissive(color=light_source.d65 * float(rng.uniform(0.5, 3))) + surface(depth + 1)
+        return surface(depth + 1) + surface(depth + 1)
+
+    def mat():
+        m = {"surface": surface()}
+        if rng.random() < 0.3:
+            m["normal_map"] = texture(tex["normal_map"], "linear") * vector(1, float(rng.choice([-1, 1])), 1)
+        return m
+
+    objects = []
+    if rng.random() < 0.7:
+        objects.append(shape.plane(origin=vector(0, 0, float(rng.uniform(-0.2, 0.2))), normal=vector(float(rng.uniform(-0.1, 0.1)), 0, 1), material=mat(),
+                                   texture_scale=vector(float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 3)))))
+    for _ in range(int(rng.integers(1, 5))):
+        r = float(rng.uniform(0.3, 1.0))
+        objects.append(shape.sphere(position=vector(float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), r + float(rng.uniform(0, 1.5))), radius=r, material=mat(),
+                                    texture_scale=vector(float(rng.uniform(0.2, 1)), float(rng.uniform(0.2, 1)))))
+    if rng.random() < 0.8:  # a few random triangles with uvs and their own normals
+        n = int(rng.integers(2, 9))
+        pos = rng.uniform(-3, 3, (3 * n, 3)).astype(f32)
+        pos[:, 2] = np.abs(pos[:, 2]) * 0.8 + 0.1
+        nrm = rng.normal(size=(3 * n, 3)).astype(f32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        mesh = {"position": pos, "texture": rng.uniform(0, 2, (3 * n, 2)).astype(f32), "normal": nrm,
+                "objects": [{"name": "soup", "polys": [[(3 * k + j, 3 * k + j, 3 * k + j if rng.random() < 0.7 else None) for j in range(3)] for k in range(n)]}]}
+        xf = transform.look_at(**{"from": vector(0, 0, 0.2), "to": vector(0.1, 0.2, -1)}) if rng.random() < 0.5 else None
+        objects.append(shape.mesh(file=mesh, materials={"soup": mat()}, scale=float(rng.uniform(0.6, 1.2)), transform=xf))
+    lamp_kinds = rng.permutation(4)[: int(rng.integers(1, 4))]
+    for k in lamp_kinds:
+        if k == 0:
+            objects.append(shape.sphere(position=vector(float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), float(rng.uniform(2.5, 4))), radius=float(rng.uniform(0.2, 0.6)),
+                                        material={"surface": material.emissive(color=light_source.d65 * float(rng.uniform(4, 12)))}))
+        elif k == 1:
+            objects.append(light.point(position=vector(float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), float(rng.uniform(3, 5))), color=light_source.a * float(rng.uniform(5, 30))))
+        elif k == 2:
+            objects.append(light.directional(direction=vector(float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4)), 0.9), width=float(rng.uniform(0.9, 0.999)),
+                                             color=blackbody(float(rng.uniform(2500, 6500))) * 3e-14))
+        else:
+            quad = {"position": np.array([[-0.5, -0.5, 3.5], [0.5, -0.5, 3.5], [0.5, 0.5, 3.6], [-0.5, 0.5, 3.6]], dtype=f32) + rng.uniform(-1, 1, 3).astype(f32) * [1, 1, 0.2],
+                    "texture": np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=f32), "normal": np.zeros((0, 3), dtype=f32),
+                    "objects": [{"name": "lamp", "polys": [[(0, 0, None), (2, 2, None), (1, 1, None)], [(0, 0, None), (3, 3, None), (2, 2, None)]]}]}
+            objects.append(shape.mesh(file=quad, materials={"lamp": {"surface": material.emissive(color=light_source.d65 * float(rng.uniform(3, 10)) * texture(tex["mono"], "mono"))}}))
+    sky = [None, light_source.d65 * float(rng.uniform(0.05, 0.3)), float(rng.uniform(0.0, 0.2))][rng.integers(0, 3)]
+    width, height = int(rng.integers(20, 49)), int(rng.integers(12, 33))
+    aperture = float(rng.uniform(0.001, 0.01)) if rng.random() < 0.3 else None
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": renderer.simple(pixel_samples=int(rng.integers(2, 7)), bounces=int(rng.integers(1, 12)), light_samples=int(rng.integers(0, 4)),
+                                    spectrum_samples=int(rng.integers(1, 9)), tile_size=int(rng.choice([8, 16, 32]))),
+        "camera": camera.perspective(fov=float(rng.uniform(35, 70)), focus_distance=6.0 if aperture else None, aperture=aperture,
+                                     transform=transform.look_at(**{"from": vector(float(rng.uniform(-1, 1)), -7, float(rng.uniform(1.5, 3.5))), "to": vector(0, 0, 1),
+                                                                    "up": vector(z=1)})),
+        "world": {"sky": sky, "objects": objects},
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "12"))))
+def test_random_scene_matches_the_oracle_on_every_scheduler(seed, gpu_lib, monkeypatch):
+    project = random_project(1000 + seed)
+    world, cam, r, _ = scenes.build(project, seed=seed)
+    width, height = project["image"]["width"], project["image"]["height"]
+    cfilm = r.new_film(width, height)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    assert np.isfinite(cfilm.grains).all()
+    for scheduler in ("sync", "sm", "wf"):
+        monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
+        gfilm = r.new_film(width, height)
+        gcount = r.render(gfilm, cam, world, counters=True)
+        assert_parity(gfilm, cfilm)
+        for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+            assert gcount[key] == ccount[key], (scheduler, key)
+
+
+def test_random_projects_are_valid_on_the_cpu():
+    """The generator itself: every project compiles and the oracle renders it to a finite film."""
+    for seed in range(12):
+        project = random_project(1000 + seed)
+        world, cam, r, film = scenes.build(project, seed=seed)
+        oracle.OracleScene(world).render(r, cam, film, threads=4)
+        assert np.isfinite(film.grains).all(), seed

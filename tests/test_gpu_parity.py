@@ -169,6 +169,31 @@ def test_closest_hit_on_a_dense_mesh(gpu_lib):
     assert (ohits["shape"] != 0xFFFFFFFF).mean() > 0.1
 
 
+def test_rays_with_a_direction_longer_than_one_pass_beside_spheres(gpu_lib):
+    """collision's sphere routine assumes a unit direction; with |d| > 1 (a directional lamp whose `direction` is not
+    normalised makes such shadow rays, lamp.rs:24-35) it reports hits for rays that pass the sphere at a distance, and the
+    reference is only saved by the leaf's bounding-box test. Leaves here hold several primitives, so spheres carry that test
+    themselves (found by tests/test_gpu_fuzz.py, seed 196)."""
+    from pyrite_amd.compiler import FlatScene
+    from pyrite_amd.project import material, shape, vector
+    from pyrite_amd.renderer import World
+
+    flat = FlatScene()
+    white = {"surface": material.diffuse(color=0.8)}
+    flat.add_world({"objects": [shape.sphere(position=vector(1.169252501331818, 1.0246223838963893, 1.4219978669133146), radius=0.3238749019030583, material=white),
+                                shape.sphere(position=vector(-1.3, 1.7, 1.0), radius=0.32, material=white),
+                                shape.sphere(position=vector(0, -2, 0.5), radius=0.5, material=white)]})
+    world = World(flat)
+    rays = np.array([[1.73444414, 0.728979588, -0.110429764, -0.123903722, 0.326353073, 0.953749716]], dtype=np.float32)
+    more = random_rays(20000, 4, [-3, -3, -1], [3, 3, 3])
+    more[:, 3:] *= np.random.RandomState(5).uniform(0.8, 1.3, (len(more), 1)).astype(np.float32)  # lengths 0.8 .. 1.3
+    rays = np.concatenate([rays, more])
+    ohits, _ = oracle.OracleScene(world).intersect(rays)
+    ghits, _, _ = world.intersect(rays)
+    assert ohits["shape"][0] == 0xFFFFFFFF and ghits["shape"][0] == 0xFFFFFFFF
+    assert np.array_equal(ohits["shape"], ghits["shape"]) and np.array_equal(ohits["distance"], ghits["distance"])
+
+
 def test_wide_and_binary_trees_answer_alike(gpu_lib, monkeypatch):
     """Scenes that do not live in LDS are walked through the 4-wide collapse of the binary tree (bvh.h Node128);
     PYRITE_WIDE_BVH=0 keeps the binary tree. Same hits, same film, fewer box tests."""

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Developer tool: python tools/fuzz_debug.py SEED -- where does the GPU film of a fuzz scene differ from the oracle's?"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle
+from pyrite_amd import scenes
+from pyrite_amd.renderer import World
+from test_gpu_fuzz import random_project
+from test_gpu_parity import rel_l2
+
+seed = int(sys.argv[1])
+project = random_project(1000 + seed)
+print("renderer", project["renderer"], "image", project["image"])
+world, cam, r, _ = scenes.build(project, seed=seed)
+W, H = project["image"]["width"], project["image"]["height"]
+print("flat: tris %d spheres %d planes %d lamps %d textures %d" % (len(world.flat.tri_material), len(world.flat.spheres), len(world.flat.planes), len(world.flat.lamps), len(world.flat.textures)))
+cfilm = r.new_film(W, H)
+cc = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+for sched in ("sync", "sm", "wf"):
+    for wide in ("1", "0"):
+        os.environ["PYRITE_SCHEDULER"], os.environ["PYRITE_WIDE_BVH"] = sched, wide
+        w2 = World(world.flat)
+        g = r.new_film(W, H)
+        gc = r.render(g, cam, w2, counters=True)
+        e = rel_l2(g, cfilm).reshape(H, W)
+        bad = np.argwhere(e > 1e-5)
+        print(sched, "wide", wide, "weights equal", np.array_equal(g.grains[..., 1], cfilm.grains[..., 1]), "bad pixels", [(int(y), int(x), float(e[y, x])) for y, x in bad][:5],
+              {k: gc[k] - cc[k] for k in ("extension_rays", "shadow_rays", "shaded_hits", "exposures")})
+        for y, x in bad[:1]:
+            d = g.grains[y, x, :, 0] - cfilm.grains[y, x, :, 0]
+            bins = np.nonzero(np.abs(d) > 1e-6 * (np.abs(cfilm.grains[y, x, :, 0]) + 1e-9))[0]
+            print("   bins", bins[:8], "gpu", g.grains[y, x, bins[:4], 0], "cpu", cfilm.grains[y, x, bins[:4], 0])
