@@ -138,3 +138,59 @@ def test_random_projects_are_valid_on_the_cpu():
         world, cam, r, film = scenes.build(project, seed=seed)
         oracle.OracleScene(world).render(r, cam, film, threads=4)
         assert np.isfinite(film.grains).all(), seed
+
+
+def random_soup(seed):
+    """A few hundred to a few thousand random triangles plus some spheres: deep trees, the 4-wide collapse, many near misses."""
+    from pyrite_amd.compiler import FlatScene
+
+    rng = np.random.default_rng(seed)
+    flat = FlatScene()
+    flat.sky_program = flat.compile(light_source.d65 * 0.3)
+    mats = [flat.add_material({"surface": s})[0] for s in (material.diffuse(color=0.7), material.mirror(color=0.9),
+                                                             material.refractive(ior=1.5, color=1, dispersion=0.01))]
+    n = int(rng.integers(150, 3000))
+    centres = rng.uniform(-4, 4, (n, 1, 3))
+    size = rng.choice([0.05, 0.3, 1.5], (n, 1, 1), p=[0.5, 0.4, 0.1])
+    pos = (centres + rng.normal(size=(n, 3, 3)) * size).astype(f32)
+    nrm = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)
+    nrm = np.repeat(nrm[:, None, :], 3, axis=1).astype(f32)
+    for k, m in enumerate(mats):
+        sel = np.arange(n) % 3 == k
+        flat.add_triangles(pos[sel], nrm[sel], m)
+    for _ in range(int(rng.integers(0, 6))):
+        flat.spheres.append([*rng.uniform(-3, 3, 3).astype(f32), f32(rng.uniform(0.2, 1.0))])
+        flat.sphere_tex_scale.append(np.array([1, 1], dtype=f32))
+        flat.sphere_material.append(mats[int(rng.integers(0, 3))])
+    emissive, _ = flat.add_material({"surface": material.emissive(color=light_source.d65 * 5)})
+    flat.spheres.append([0.0, 0.0, 6.0, 0.7])
+    flat.sphere_tex_scale.append(np.array([1, 1], dtype=f32))
+    flat.sphere_material.append(emissive)
+    from pyrite_amd import abi
+    flat.lamps.append(dict(kind=abi.LAMP_SHAPE, shape_kind=abi.SHAPE_SPHERE, shape_index=len(flat.spheres) - 1))
+    return flat
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "6"))))
+def test_random_soup_hits_and_film_match_the_oracle(seed, gpu_lib, monkeypatch):
+    from pyrite_amd.renderer import Camera, Renderer, World
+    from test_gpu_parity import assert_same_hits, random_rays
+
+    world = World(random_soup(2000 + seed))
+    # unit directions: with |d| != 1 the reference compares a sphere's Euclidean distance with a box's parametric one when it
+    # prunes, and which hit survives then depends on the order its own tree is walked in
+    rays = random_rays(30000, seed, [-5, -5, -5], [5, 5, 5])
+    ohits, _ = oracle.OracleScene(world).intersect(rays)
+    ghits, _, _ = world.intersect(rays)
+    assert_same_hits(ohits, ghits)
+    r = Renderer(pixel_samples=3, bounces=6, light_samples=2, spectrum_samples=5, tile_size=16, seed=seed)
+    cam = Camera.from_project(camera.perspective(fov=60, transform=transform.look_at(**{"from": vector(0, -9, 1), "to": vector(0, 0, 0), "up": vector(z=1)})))
+    cfilm = r.new_film(40, 30)
+    oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    for scheduler in ("sm", "wf", "sync"):
+        monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
+        gfilm = r.new_film(40, 30)
+        r.render(gfilm, cam, world)
+        assert_parity(gfilm, cfilm)
