@@ -118,7 +118,7 @@ def desc_bytes(world):
     out["programs"], out["instrs"], out["materials"], out["components"] = flat.programs, flat.instrs, flat.materials, flat.components
     out["spectra"], out["spectrum_data"] = flat.spectra, list(flat.spectrum_data)
     out["spheres"], out["planes"], out["lamps"] = np.asarray(flat.spheres).tolist(), np.asarray(flat.planes).tolist(), repr(flat.lamps)
-    out["tris"] = np.concatenate([np.asarray(t).reshape(-1) for t in flat.tri_positions]).tolist()
+    out["tris"] = [np.asarray(t).reshape(-1).tolist() for t in flat.tri_positions]
     out["textures"] = [(f, t.tobytes()) for f, t in flat.textures]
     return out
 
@@ -147,3 +147,33 @@ def test_gpu_renders_a_project_file(gpu_lib):
     oracle.OracleScene(world).render(r, cam, cpu, threads=8)
     r.render(film, cam, world)
     assert_parity(film, cpu)
+
+
+REFERENCE_TESTS = "/root/reference/pyrite/test"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_TESTS), reason="the reference checkout only exists in the build container")
+@pytest.mark.parametrize("name,restated", [("spheres", lambda: scenes.spheres_example(512, 256, 600)),
+                                           ("diamonds", lambda: scenes.diamonds_example(512, 300, 200, bounces=256))])
+def test_the_reference_projects_load_and_equal_the_restated_scenes(name, restated):
+    """pyrite/test/<name>/<name>.lua read by the loader == the scene pyrite_amd/scenes.py restates by hand (the one the
+    reference-image tests render): same camera, renderer parameters and flattened world."""
+    project, base_dir = lua_project.load_project(os.path.join(REFERENCE_TESTS, name, name + ".lua"))
+    lua_world, lua_cam, lua_r, lua_film = scenes.build(project, seed=1, base_dir=base_dir)
+    py_world, py_cam, py_r, py_film = scenes.build(restated(), seed=1)
+    assert desc_bytes(lua_world) == desc_bytes(py_world)
+    assert bytes(lua_cam.c) == bytes(py_cam.c)
+    for key in ("pixel_samples", "bounces", "light_samples", "spectrum_samples", "spectrum_bins", "tile_size"):
+        assert getattr(lua_r, key) == getattr(py_r, key), key
+    assert (lua_film.width, lua_film.height, lua_film.bins) == (py_film.width, py_film.height, py_film.bins)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_TESTS), reason="the reference checkout only exists in the build container")
+def test_every_reference_project_file_parses():
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(REFERENCE_TESTS, "*", "*.lua"))):
+        if os.path.basename(path) in ("materials.lua", "lamp.lua") or path.endswith("cornell/colors.lua"):
+            continue  # modules that other projects `require`
+        project, _ = lua_project.load_project(path)
+        assert project["renderer"].type in ("simple", "bidirectional", "photon_mapping") and len(project["world"]["objects"]) >= 1, path
