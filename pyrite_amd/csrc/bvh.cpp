@@ -160,7 +160,7 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
         if (best_axis >= 0) {
             // SAH termination: a leaf costs `count` primitive tests, a split costs one node visit plus the children.
             float parent_area = box.half_area();
-            float split_cost = 1.0f + (parent_area > 0.0f ? best_cost / parent_area : kInf);
+            float split_cost = kSahNodeCost + (parent_area > 0.0f ? best_cost / parent_area : kInf);
             if (count <= kMaxLeafPrims && (float)count <= split_cost) return false;
             float extent = cbox.hi[best_axis] - cbox.lo[best_axis];
             float scale = (float)kBins / extent;

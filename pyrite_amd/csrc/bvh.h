@@ -44,6 +44,10 @@ struct BuiltBvh {
 #endif
 constexpr uint32_t kMaxLeafPrims = PYR_MAX_LEAF; // <= 7: the leaf code keeps the count in 3 bits
 constexpr uint32_t kMaxBvhDepth = 40;
+#ifndef PYR_SAH_NODE_COST
+#define PYR_SAH_NODE_COST 1.0f
+#endif
+constexpr float kSahNodeCost = PYR_SAH_NODE_COST; // cost of one node visit in units of one primitive test (SAH termination)
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return -1 - (int32_t)((first << 3) | count); }
 
