@@ -43,14 +43,45 @@ def build_images(force=False, verbose=False):
     return IMAGES_OUT
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_OUT = os.path.join(HOST_DIR, "libpyrite_host.so")
+HOST_TOOL = os.path.join(HOST_DIR, "pyrite_host_tool")
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-I" + os.path.join(CSRC, "..", "..", "include")]
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host layer above the C ABI (include/pyrite_host.hpp): libpyrite_host.so + pyrite_host_tool, plain g++.
+    Both link libpyrite_gpu.so (rpath $ORIGIN/..), which must exist."""
+    deps = [os.path.join(HOST_DIR, f) for f in ("pyrite_host.cpp", "builtin_tables.inc")] + [os.path.join(CSRC, "..", "..", "include", h)
+                                                                                           for h in ("pyrite_host.hpp", "pyrite_gpu.h")]
+    cxx = os.environ.get("CXX", "g++")
+
+    def newer(out, sources):
+        return not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in sources)
+
+    if force or newer(HOST_OUT, deps + [OUT]):
+        cmd = [cxx] + HOST_FLAGS + ["-shared", "pyrite_host.cpp", "-L" + CSRC, "-lpyrite_gpu", "-Wl,-rpath,$ORIGIN/..", "-o", HOST_OUT]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=HOST_DIR)
+    tool_src = os.path.join(HOST_DIR, "pyrite_host_tool.cpp")
+    if force or newer(HOST_TOOL, deps + [tool_src, HOST_OUT]):
+        cmd = [cxx] + HOST_FLAGS + ["pyrite_host_tool.cpp", "-L" + HOST_DIR, "-lpyrite_host", "-L" + CSRC, "-lpyrite_gpu", "-Wl,-rpath,$ORIGIN",
+                                    "-Wl,-rpath,$ORIGIN/..", "-o", HOST_TOOL]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=HOST_DIR)
+    return HOST_OUT
+
+
 def build(force=False, extra_flags=(), verbose=False):
     build_images(force, verbose)
-    if not force and not stale():
-        return OUT
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    if force or stale():
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    build_host(force, verbose)
     return OUT
 
 

@@ -1,0 +1,123 @@
+"""The C++ host layer (include/pyrite_host.hpp, libpyrite_host.so) against the Python front-end and the oracle.
+
+CPU: every scene of pyrite_host_tool, written against the C++ surface, flattens to the same bytes as the same scene written
+against the Python surface (program compiler, material flattening, world flattening, OBJ ingest, tangent frames, textures,
+camera and renderer parameters). GPU: Renderer::render through the C++ seam gives the oracle's film."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from pyrite_amd import abi, build as gpu_build, images, scenes
+from pyrite_amd.compiler import DATA_DIR, FlatScene, camera_from_project, renderer_from_project
+
+HOST_LIB, HOST_TOOL = gpu_build.HOST_OUT, gpu_build.HOST_TOOL
+
+SCENES = {
+    "c1": scenes.c1_spheres,
+    "c2": scenes.c2_cornell,
+    "spheres": scenes.spheres_example,
+    "diamonds": scenes.diamonds_example,
+    "lamps": scenes.lamps_example,
+    "textures": scenes.textures_example,
+}
+
+
+@pytest.fixture(scope="module")
+def host():
+    gpu_build.build_host()
+    lib = C.CDLL(HOST_LIB)
+    lib.pyrh_serialize_desc.restype = C.c_uint64
+    lib.pyrh_serialize_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    return lib
+
+
+def scene_bytes(lib, desc):
+    n = lib.pyrh_serialize_desc(C.byref(desc), None, 0)
+    buf = (C.c_uint8 * n)()
+    assert lib.pyrh_serialize_desc(C.byref(desc), buf, n) == n
+    return bytes(buf)
+
+
+def data_dir_for(name, tmp_path):
+    """The textures scene reads its texel arrays (linear f32, as Texture::from_path leaves them) from files."""
+    if name != "textures":
+        return DATA_DIR
+    tex = scenes._generated_textures()
+    for fname, source, linear, mono in (("checker", tex["checker"], False, False), ("nmap_linear", tex["normal_map"], True, False),
+                                        ("rgba", tex["rgba"], False, False), ("mono_linear", tex["mono"], True, True),
+                                        ("mono_srgb", tex["mono"], False, True)):
+        images.linearise(source, linear, mono).astype("<f4").tofile(os.path.join(tmp_path, fname + ".f32"))
+    return str(tmp_path)
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_cpp_front_end_flattens_like_the_python_front_end(host, name, tmp_path):
+    project = SCENES[name]()
+    flat = FlatScene().add_world(project["world"], DATA_DIR)
+    expected = scene_bytes(host, flat.desc())
+    out = os.path.join(tmp_path, "scene.bin")
+    subprocess.check_call([HOST_TOOL, "dump", name, data_dir_for(name, tmp_path), out], stdout=subprocess.DEVNULL)
+    with open(out, "rb") as f:
+        got = f.read()
+    assert got[:len(expected)] == expected, "flattened scene differs"
+    rest = got[len(expected):]
+    cam = np.frombuffer(rest[:C.sizeof(abi.PyrCamera)], dtype=np.float32)
+    want = np.frombuffer(bytes(camera_from_project(project["camera"])), dtype=np.float32)
+    # cos / sin of the half angle come from two libms: allow an ulp or two on view_plane, nothing elsewhere
+    assert np.array_equal(cam[:16], want[:16]) and np.array_equal(cam[17:], want[17:])
+    assert abs(cam[16] - want[16]) <= 4e-7 * abs(want[16])
+    r = renderer_from_project(project["renderer"])
+    params = np.frombuffer(rest[C.sizeof(abi.PyrCamera):], dtype=np.uint32)
+    assert list(params[[0, 2, 3, 4, 5]]) == [r["bounces"], r["light_samples"], r["spectrum_samples"], r["spectrum_bins"], r["tile_size"]]
+
+
+def test_missing_mesh_material_is_a_project_error(host, tmp_path):
+    """world.rs:199-208: an OBJ object without a material entry is reported, not skipped."""
+    obj = os.path.join(tmp_path, "cornell_box.obj")
+    with open(os.path.join(DATA_DIR, "cornell_box.obj")) as f, open(obj, "w") as g:
+        g.write(f.read() + "\no extra\nf 1 2 3\n")
+    with open(os.path.join(DATA_DIR, "cornell_spectra.json")) as f, open(os.path.join(tmp_path, "cornell_spectra.json"), "w") as g:
+        g.write(f.read())
+    p = subprocess.run([HOST_TOOL, "dump", "c2", str(tmp_path), os.path.join(tmp_path, "x.bin")], capture_output=True, text=True)
+    assert p.returncode == 1 and "missing material for 'extra'" in p.stderr
+
+
+def test_png_writer_and_evaluate_at(host, tmp_path):
+    """save_png output decodes to the pixels given (stored deflate blocks, CRCs, Adler-32)."""
+    lib = host
+    lib.pyrh_test_png.restype = C.c_int
+    lib.pyrh_test_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (150, 301, 3), dtype=np.uint8)  # > 65535 bytes of scanlines: more than one stored block
+    path = os.path.join(tmp_path, "x.png")
+    assert lib.pyrh_test_png(path.encode(), rgb.ctypes.data, 301, 150) == 0
+    assert np.array_equal(images.read_png(path), rgb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,width,height,spp", [("c2", 64, 64, 8), ("lamps", 48, 32, 8), ("textures", 48, 32, 4)])
+def test_cpp_renderer_seam_matches_the_oracle(host, name, width, height, spp, tmp_path):
+    import oracle
+
+    film_path, png_path = os.path.join(tmp_path, "film.bin"), os.path.join(tmp_path, "out.png")
+    out = subprocess.check_output([HOST_TOOL, "render", name, data_dir_for(name, tmp_path), str(width), str(height), str(spp), "3", film_path, png_path], text=True)
+    assert "The scene contains" in out and "100 %" in out
+    project = SCENES[name](width, height, spp)
+    world, cam, r, cpu_film = scenes.build(project, seed=3, base_dir=DATA_DIR)
+    gpu = np.fromfile(film_path, dtype=np.float32).reshape(height, width, r.spectrum_bins, 2)
+    oracle.OracleScene(world).render(r, cam, cpu_film, threads=4)
+    assert np.array_equal(gpu[..., 1], cpu_film.grains[..., 1]), "film weights differ from the oracle"
+    a = np.divide(gpu[..., 0], gpu[..., 1], out=np.zeros_like(gpu[..., 0]), where=gpu[..., 1] > 0)
+    b = cpu_film.develop()
+    e = np.sqrt(((a - b) ** 2).sum(-1)) / (np.sqrt((b ** 2).sum(-1)) + 1e-6)
+    assert (e <= 1e-5).mean() >= 0.999, "per-pixel spectral relL2 vs oracle: max %.3g" % e.max()
+    # the developed image written by the C++ side equals the Python front-end's development of the same film
+    from pyrite_amd import develop
+    from pyrite_amd.film import Film
+
+    f = Film(width, height, r.spectrum_bins, r.spectrum_span)
+    f.grains[...] = gpu
+    assert np.array_equal(images.read_png(png_path), develop.develop(f))
