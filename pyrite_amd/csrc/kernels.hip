@@ -1191,9 +1191,14 @@ DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_bef
 // the 10-wavelength work cost 139 of 250 ms). When they fit they are copied into LDS once per workgroup; the scene copy
 // handed to the device functions then points at the LDS copy (generic pointers: the loads become flat loads that resolve
 // to LDS).
+// TABLES is a compile-time statement of where the tables live (0: HBM, as the kernel arguments point; 1: staged into LDS;
+// -1: decided at run time from S.lds_table_floats). With a run-time choice the pointers are generic and every table access
+// is a flat_load that must drain both vmcnt and lgkmcnt (MI355X_MICROARCH.md: flat completes out of order); with a
+// compile-time one they are global_load / s_load or ds_read.
+template <int TABLES>
 DEV DevScene stage_tables(const DevScene& S, float* lds, uint32_t lds_floats_before) {
     DevScene local = S;
-    if (S.lds_table_floats != 0) {
+    if (TABLES == 1 || (TABLES == -1 && S.lds_table_floats != 0)) {
         float* dst = lds + lds_floats_before;
         const uint32_t rec_floats = S.num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float));
         const float* rec_src = reinterpret_cast<const float*>(S.spectra);
@@ -1520,7 +1525,7 @@ DEV void finish_path(const RenderLaunch& L, const Path& p, Spectral& spec, Count
 //   * refilling a lane as soon as its path ends (one bounce per loop turn)                         0.60x
 //   * parking survivors of the first two bounces in a ballot-compacted HBM queue for a tail kernel  0.93x
 // (MI355X, C2, 64 spp; both were built and measured, see DESIGN.md "Scheduling experiments").
-template <bool COUNT, bool INTERP, bool LDS_SCENE>
+template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
@@ -1529,7 +1534,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
     Counters cnt{};
     const uint32_t lds_base_floats = (3 * SS + S0.stack_depth) * BLOCK;
     const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats);
-    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
+    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = BLOCK / 64;
@@ -2084,7 +2089,7 @@ struct Walker {
     }
 };
 
-template <bool COUNT, bool INTERP, bool LDS_SCENE>
+template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
@@ -2095,7 +2100,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
     Counters cnt{};
     const uint32_t lds_base_floats = (3 * SS + L.stack_lds) * BLOCK;
     const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats, true);
-    const DevScene S = stage_tables(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
+    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t waves_per_block = BLOCK / 64;
@@ -2364,7 +2369,7 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderL
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
     Counters cnt{};
-    const DevScene S = stage_tables(S0, lds, 3 * SS * BLOCK);
+    const DevScene S = stage_tables<-1>(S0, lds, 3 * SS * BLOCK);
     if (blockIdx.x == 0 && threadIdx.x < kFeedSegments) P.next[threadIdx.x * kFeedCursorStride] = 0; // the traversal kernel that follows starts afresh
     // The workgroup owns BLOCK consecutive slots. Its threads take them sorted by entry stage (SHADE, NEE, NEW, done) so that
     // a wave runs one phase body instead of every body at partial occupancy; the slots stay within one 4 KB window per state
@@ -2592,14 +2597,18 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
 }
 
 using RenderKernel = void (*)(DevScene, RenderLaunch);
-static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene) {
-    static const RenderKernel sync[2][2][2] = {
-        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
-        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
-    static const RenderKernel staged[2][2][2] = {
-        {{render_kernel_sm<false, false, false>, render_kernel_sm<false, false, true>}, {render_kernel_sm<false, true, false>, render_kernel_sm<false, true, true>}},
-        {{render_kernel_sm<true, false, false>, render_kernel_sm<true, false, true>}, {render_kernel_sm<true, true, false>, render_kernel_sm<true, true, true>}}};
-    return (sm ? staged : sync)[with_counters ? 1 : 0][interp ? 1 : 0][lds_scene ? 1 : 0];
+template <bool C, bool I, bool L>
+static RenderKernel pick_tables(bool sm, bool lds_tables) {
+    if (sm) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
+    return lds_tables ? render_kernel<C, I, L, true> : render_kernel<C, I, L, false>;
+}
+template <bool C, bool I>
+static RenderKernel pick_scene(bool sm, bool lds_scene, bool lds_tables) {
+    return lds_scene ? pick_tables<C, I, true>(sm, lds_tables) : pick_tables<C, I, false>(sm, lds_tables);
+}
+static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables) {
+    if (with_counters) return interp ? pick_scene<true, true>(sm, lds_scene, lds_tables) : pick_scene<true, false>(sm, lds_scene, lds_tables);
+    return interp ? pick_scene<false, true>(sm, lds_scene, lds_tables) : pick_scene<false, false>(sm, lds_scene, lds_tables);
 }
 
 bool scene_is_lds_resident(const DevScene& scene) { return scene_fits_lds(scene); }
@@ -2620,7 +2629,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     }
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
-    RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene));
+    RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0);
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
