@@ -300,6 +300,22 @@ class Renderer { // renderer/mod.rs:18-28, Algorithm::Simple
                 PyrCounters* counters = nullptr) const;
 };
 
+// ------------------------------------------------------------------------------------------------ project files
+// Reads a project file (*.lua): the declarative subset of Lua project files are written in, evaluated against the prelude
+// of pyrite/src/project/lib.lua, then typed_nodes' FromLua step (pyrite_amd/csrc/host/lua_project.cpp; main.rs:111-134).
+// Image files are decoded by `textures`, which turns (absolute path, linear?, mono?) into linear f32 texels
+// ([height][width][4] or [height][width]) -- what Texture::from_path does (texture.rs:25-85). One texture per (file, kind).
+using TextureLoader = std::function<std::vector<float>(const std::string& path, bool linear, bool mono, uint32_t& width, uint32_t& height)>;
+struct LoadedProject {
+    Project project;
+    std::string base_dir; // mesh and texture paths are relative to the project file's directory (project/mod.rs:73-76)
+};
+// The built-in decoder: PNG and baseline JPEG files -> linear texels (pyrite_amd/csrc/host/images.cpp). It is what
+// load_project / evaluate_project use when no loader is given.
+std::vector<float> load_texture_file(const std::string& path, bool linear, bool mono, uint32_t& width, uint32_t& height);
+LoadedProject load_project(const std::string& path, const TextureLoader& textures = nullptr);
+LoadedProject evaluate_project(const std::string& text, const std::string& name, const std::string& base_dir, const TextureLoader& textures = nullptr);
+
 // Value of a wavelength-only expression with the VM's f32 arithmetic (image.filter / image.white, main.rs:470-518).
 float evaluate_at(const Expression& expression, float wavelength);
 
@@ -309,6 +325,7 @@ float evaluate_at(const Expression& expression, float wavelength);
 // bytes. Test infrastructure for comparing front-ends; returns the size needed, writes at most `capacity` bytes.
 extern "C" uint64_t pyrh_serialize_desc(const PyrSceneDesc* desc, uint8_t* out, uint64_t capacity);
 // pyrite::save_png through a C entry point (tests). Returns 0 on success.
+extern "C" int64_t pyrh_test_load_texture(const char* path, int linear, int mono, float* out, uint64_t capacity, uint32_t* width, uint32_t* height);
 extern "C" int pyrh_test_png(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height);
 
 #endif // PYRITE_HOST_HPP

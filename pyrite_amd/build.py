@@ -52,7 +52,7 @@ HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-I" +
 def build_host(force=False, verbose=False):
     """The C++ host layer above the C ABI (include/pyrite_host.hpp): libpyrite_host.so + pyrite_host_tool, plain g++.
     Both link libpyrite_gpu.so (rpath $ORIGIN/..), which must exist."""
-    deps = [os.path.join(HOST_DIR, f) for f in ("pyrite_host.cpp", "builtin_tables.inc")] + [os.path.join(CSRC, "..", "..", "include", h)
+    deps = [os.path.join(HOST_DIR, f) for f in ("pyrite_host.cpp", "lua_project.cpp", "images.cpp", "builtin_tables.inc")] + [os.path.join(CSRC, "jpeg.c")] + [os.path.join(CSRC, "..", "..", "include", h)
                                                                                            for h in ("pyrite_host.hpp", "pyrite_gpu.h")]
     cxx = os.environ.get("CXX", "g++")
 
@@ -60,7 +60,11 @@ def build_host(force=False, verbose=False):
         return not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in sources)
 
     if force or newer(HOST_OUT, deps + [OUT]):
-        cmd = [cxx] + HOST_FLAGS + ["-shared", "pyrite_host.cpp", "-L" + CSRC, "-lpyrite_gpu", "-Wl,-rpath,$ORIGIN/..", "-o", HOST_OUT]
+        jpeg = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-c", os.path.join(CSRC, "jpeg.c"), "-o", os.path.join(HOST_DIR, "jpeg.o")]
+        if verbose:
+            print(" ".join(jpeg))
+        subprocess.check_call(jpeg, cwd=HOST_DIR)
+        cmd = [cxx] + HOST_FLAGS + ["-shared", "pyrite_host.cpp", "lua_project.cpp", "images.cpp", "jpeg.o", "-L" + CSRC, "-lpyrite_gpu", "-Wl,-rpath,$ORIGIN/..", "-o", HOST_OUT]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=HOST_DIR)

@@ -1282,6 +1282,16 @@ extern "C" int pyrh_test_png(const char* path, const uint8_t* rgb, uint32_t widt
     }
 }
 
+extern "C" int64_t pyrh_test_load_texture(const char* path, int linear, int mono, float* out, uint64_t capacity, uint32_t* width, uint32_t* height) {
+    try {
+        const std::vector<float> texels = pyrite::load_texture_file(path, linear != 0, mono != 0, *width, *height);
+        if (texels.size() <= capacity) std::memcpy(out, texels.data(), texels.size() * sizeof(float));
+        return (int64_t)texels.size();
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
 // canonical scene bytes
 extern "C" uint64_t pyrh_serialize_desc(const PyrSceneDesc* d, uint8_t* out, uint64_t capacity) {
     uint64_t size = 0;

@@ -2,6 +2,8 @@
 // (include/pyrite_host.hpp), the way pyrite_amd/scenes.py writes them against the Python surface.
 //
 //   pyrite_host_tool dump   <scene> <data_dir> <out.bin>                      flatten only (no GPU): canonical scene bytes + camera + renderer
+//   pyrite_host_tool dump-project   <project.lua> <texel dir | -> <out.bin>    the same for a project file (lua_project.cpp)
+//   pyrite_host_tool render-project <project.lua> <texel dir | -> <seed> <out.png> [film.bin]   what `pyrite project.lua` does (main.rs:46-330)
 //   pyrite_host_tool render <scene> <data_dir> <w> <h> <spp> <seed> <film.bin> [out.png]
 //                                                                             Renderer::render on device 0; film as raw {acc, weight} f32
 // scenes: c1 c2 spheres diamonds lamps textures      data_dir: pyrite_amd/data (cornell_spectra.json, cornell_box.obj, diamonds.obj)
@@ -193,23 +195,69 @@ static Project make_scene(const std::string& name, const std::string& data_dir) 
     throw ProjectError("unknown scene " + name);
 }
 
+// Texels for project files: <dir>/<file name>.<linear|srgb>.<mono|color>.f32 = u32 width, u32 height, f32 texels (already
+// linear) -- written by whoever decodes the images (tests: pyrite_amd/images.py).
+static TextureLoader texel_files(const std::string& dir) {
+    return [dir](const std::string& path, bool linear, bool mono, uint32_t& width, uint32_t& height) {
+        const size_t slash = path.find_last_of('/');
+        const std::string file = dir + "/" + path.substr(slash == std::string::npos ? 0 : slash + 1) + (linear ? ".linear" : ".srgb") + (mono ? ".mono" : ".color") + ".f32";
+        std::ifstream f(file, std::ios::binary);
+        uint32_t wh[2] = {0, 0};
+        if (!f.read(reinterpret_cast<char*>(wh), 8)) throw ProjectError("could not load " + path + " (no " + file + ")");
+        width = wh[0], height = wh[1];
+        std::vector<float> texels((size_t)width * height * (mono ? 1 : 4));
+        if (!f.read(reinterpret_cast<char*>(texels.data()), (std::streamsize)(texels.size() * 4))) throw ProjectError("short texel file " + file);
+        return texels;
+    };
+}
+
+static void write_dump(const char* path, FlatScene& flat, const Project& project) {
+    const PyrSceneDesc& d = flat.desc();
+    std::vector<uint8_t> bytes(pyrh_serialize_desc(&d, nullptr, 0));
+    pyrh_serialize_desc(&d, bytes.data(), bytes.size());
+    const Camera cam = Camera::from_project(project.camera);
+    const Renderer r = Renderer::from_project(project.renderer);
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(bytes.data()), (std::streamsize)bytes.size());
+    f.write(reinterpret_cast<const char*>(&cam.c), sizeof(cam.c));
+    const uint32_t params[8] = {r.bounces, r.pixel_samples, r.light_samples, r.spectrum_samples, r.spectrum_bins, r.tile_size, project.image.width, project.image.height};
+    f.write(reinterpret_cast<const char*>(params), sizeof(params));
+    std::printf("%zu scene bytes, %zu triangles, %zu spheres, %zu planes\n", bytes.size(), flat.num_triangles(), flat.num_spheres(), flat.num_planes());
+}
+
 int main(int argc, char** argv) {
     try {
+        if (argc >= 5 && std::string(argv[1]) == "dump-project") { // dump-project <project.lua> <texel dir | -> <out.bin>
+            const LoadedProject loaded = load_project(argv[2], std::string(argv[3]) == "-" ? TextureLoader() : texel_files(argv[3]));
+            FlatScene flat;
+            flat.add_world(loaded.project.world, loaded.base_dir);
+            write_dump(argv[4], flat, loaded.project);
+            return 0;
+        }
+        if (argc >= 6 && std::string(argv[1]) == "render-project") { // render-project <project.lua> <texel dir | -> <seed> <out.png> [film.bin]
+            const LoadedProject loaded = load_project(argv[2], std::string(argv[3]) == "-" ? TextureLoader() : texel_files(argv[3]));
+            const Project& project = loaded.project;
+            std::unique_ptr<World> world = World::from_project(project.world, loaded.base_dir);
+            const Camera cam = Camera::from_project(project.camera);
+            Renderer r = Renderer::from_project(project.renderer);
+            r.seed = std::strtoull(argv[4], nullptr, 10);
+            Film film = r.new_film(project.image.width, project.image.height);
+            std::printf("The scene contains %zu objects.\n", world->num_objects()); // world.rs:251-254
+            r.render(film, cam, *world);
+            std::printf("Saving final result...\n"); // main.rs:313
+            save_png(argv[5], film.develop(project.image.filter, project.image.white), film.width, film.height);
+            if (argc >= 7) {
+                std::ofstream f(argv[6], std::ios::binary);
+                f.write(reinterpret_cast<const char*>(film.grains.data()), (std::streamsize)(film.grains.size() * sizeof(PyrGrain)));
+            }
+            return 0;
+        }
         if (argc >= 5 && std::string(argv[1]) == "dump") {
             Project project = make_scene(argv[2], argv[3]);
             FlatScene flat;
             flat.add_world(project.world, argv[3]);
-            const PyrSceneDesc& d = flat.desc();
-            std::vector<uint8_t> bytes(pyrh_serialize_desc(&d, nullptr, 0));
-            pyrh_serialize_desc(&d, bytes.data(), bytes.size());
-            const Camera cam = Camera::from_project(project.camera);
-            const Renderer r = Renderer::from_project(project.renderer);
-            std::ofstream f(argv[4], std::ios::binary);
-            f.write(reinterpret_cast<const char*>(bytes.data()), (std::streamsize)bytes.size());
-            f.write(reinterpret_cast<const char*>(&cam.c), sizeof(cam.c));
-            const uint32_t params[6] = {r.bounces, r.pixel_samples, r.light_samples, r.spectrum_samples, r.spectrum_bins, r.tile_size};
-            f.write(reinterpret_cast<const char*>(params), sizeof(params));
-            std::printf("%s: %zu scene bytes, %zu triangles, %zu spheres, %zu planes\n", argv[2], bytes.size(), flat.num_triangles(), flat.num_spheres(), flat.num_planes());
+            std::printf("%s: ", argv[2]);
+            write_dump(argv[4], flat, project);
             return 0;
         }
         if (argc >= 9 && std::string(argv[1]) == "render") {

@@ -121,3 +121,138 @@ def test_cpp_renderer_seam_matches_the_oracle(host, name, width, height, spp, tm
     f = Film(width, height, r.spectrum_bins, r.spectrum_span)
     f.grains[...] = gpu
     assert np.array_equal(images.read_png(png_path), develop.develop(f))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/pyrite/test/textures/color_checker.jpg"), reason="the reference checkout only exists in the build container")
+def test_cpp_jpeg_textures_match_the_python_reader(host):
+    host.pyrh_test_load_texture.restype = C.c_int64
+    host.pyrh_test_load_texture.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    path = "/root/reference/pyrite/test/textures/color_checker.jpg"
+    want = images.load_texture(path, False, False)
+    buf = np.zeros(want.size, dtype=np.float32)
+    w, h = C.c_uint32(), C.c_uint32()
+    assert host.pyrh_test_load_texture(path.encode(), 0, 0, buf.ctypes.data, buf.size, C.byref(w), C.byref(h)) == want.size
+    assert np.array_equal(buf.view(np.uint32), np.ascontiguousarray(want).reshape(-1).view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ project files (lua_project.cpp)
+PROJECTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "projects")
+REFERENCE_TESTS = "/root/reference/pyrite/test"
+
+
+def flatten_with_python(path, texel_dir):
+    """Python front-end: project file -> scene bytes; leaves the textures it decoded as texel files for the C++ side."""
+    from pyrite_amd import lua_project
+
+    project, base_dir = lua_project.load_project(path)
+    flat = FlatScene().add_world(project["world"], base_dir)
+    for (source, linear, mono), tid in flat._texture_ids.items():
+        texels = np.ascontiguousarray(flat.textures[tid][1], dtype="<f4")
+        name = "%s.%s.%s.f32" % (os.path.basename(source), "linear" if linear else "srgb", "mono" if mono else "color")
+        with open(os.path.join(texel_dir, name), "wb") as f:
+            f.write(np.array([texels.shape[1], texels.shape[0]], dtype="<u4").tobytes())
+            f.write(texels.tobytes())
+    return project, flat
+
+
+def check_project_file(host, path, tmp_path, native_images=True):
+    project, flat = flatten_with_python(path, str(tmp_path))
+    expected = scene_bytes(host, flat.desc())
+    out = os.path.join(tmp_path, "scene.bin")
+    subprocess.check_call([HOST_TOOL, "dump-project", path, "-" if native_images else str(tmp_path), out], stdout=subprocess.DEVNULL)
+    with open(out, "rb") as f:
+        got = f.read()
+    assert got[:len(expected)] == expected, "flattened scene differs"
+    rest = got[len(expected):]
+    cam = np.frombuffer(rest[:C.sizeof(abi.PyrCamera)], dtype=np.float32)
+    want = np.frombuffer(bytes(camera_from_project(project["camera"])), dtype=np.float32)
+    assert np.array_equal(cam[:16], want[:16]) and np.array_equal(cam[17:], want[17:]) and abs(cam[16] - want[16]) <= 4e-7 * abs(want[16])
+    r = renderer_from_project(project["renderer"])
+    params = np.frombuffer(rest[C.sizeof(abi.PyrCamera):], dtype=np.uint32)
+    image = project.get("image") or {}
+    assert list(params) == [r["bounces"], r["pixel_samples"], r["light_samples"], r["spectrum_samples"], r["spectrum_bins"], r["tile_size"],
+                            image.get("width", 0), image.get("height", 0)]
+
+
+@pytest.mark.parametrize("texels", ["decoded by the C++ side", "handed over as texel files"])
+def test_cpp_project_file_reader_matches_the_python_one(host, tmp_path, texels):
+    """gallery.lua: locals, require, :with{} chains, table / string / parenthesised calls, arithmetic on expressions, textures,
+    a normal map, an OBJ mesh, every lamp kind. Its PNG textures are decoded natively (images.cpp) or come through the hook."""
+    check_project_file(host, os.path.join(PROJECTS, "gallery.lua"), tmp_path, native_images=texels.startswith("decoded"))
+
+
+@pytest.mark.parametrize("name", sorted(os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures"))))
+def test_cpp_image_decoder_matches_the_python_one(host, name, tmp_path):
+    """PNG (inflate, filters, colour types) and baseline JPEG -> linear texels, bit for bit, for every texture fixture."""
+    host.pyrh_test_load_texture.restype = C.c_int64
+    host.pyrh_test_load_texture.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures", name)
+    if os.path.splitext(name)[1].lower() not in (".png", ".jpg", ".jpeg"):
+        pytest.skip("not an image")
+    for linear, mono in ((False, False), (True, False), (False, True), (True, True)):
+        want = images.load_texture(path, linear, mono)
+        buf = np.zeros(want.size, dtype=np.float32)
+        w, h = C.c_uint32(), C.c_uint32()
+        n = host.pyrh_test_load_texture(path.encode(), int(linear), int(mono), buf.ctypes.data, buf.size, C.byref(w), C.byref(h))
+        assert n == want.size and (h.value, w.value) == want.shape[:2]
+        assert np.array_equal(buf.view(np.uint32), np.ascontiguousarray(want).reshape(-1).view(np.uint32))
+
+
+def test_cpp_project_file_errors_name_file_and_line(host, tmp_path):
+    def run(text):
+        path = os.path.join(tmp_path, "p.lua")
+        with open(path, "w") as f:
+            f.write(text)
+        p = subprocess.run([HOST_TOOL, "dump-project", path, "-", os.path.join(tmp_path, "x.bin")], capture_output=True, text=True)
+        assert p.returncode == 1
+        return p.stderr
+
+    assert "p.lua:2: attempt to call a nil value (global 'sphere')" in run("local a = 1\nreturn sphere {radius = 1}")
+    assert "function definitions are not supported" in run("local f = function(x) return x end return f(1)")
+    assert "'for' is not supported" in run("for i = 1, 3 do end")
+    assert "renderer.bidirectional is out of scope" in run(
+        "return {camera = camera.perspective {fov = 40, transform = transform.look_at {from = vector(0, 0, 5), to = vector()}},"
+        " renderer = renderer.bidirectional {pixel_samples = 1}, world = {objects = {}}}")
+    assert "a.png: no such file" in run(
+        "return {camera = camera.perspective {fov = 40, transform = transform.look_at {from = vector(0, 0, 5), to = vector()}},"
+        " renderer = renderer.simple {pixel_samples = 1}, world = {objects = {shape.sphere {position = vector(), radius = 1,"
+        " material = {surface = material.diffuse {color = texture 'a.png'}}}}}}")
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_TESTS), reason="the reference checkout only exists in the build container")
+@pytest.mark.parametrize("name", ["spheres/spheres.lua", "diamonds/diamonds.lua", "textures/textures.lua", "colors/colors.lua", "rgb_emission/rgb_emission.lua",
+                                  "rgb_reflection/rgb_reflection.lua"])
+def test_cpp_reads_the_reference_project_files_like_the_python_reader(host, name, tmp_path):
+    from pyrite_amd import lua_project
+    from pyrite_amd.compiler import ProjectError
+
+    path = os.path.join(REFERENCE_TESTS, name)
+    try:
+        project, _ = flatten_with_python(path, str(tmp_path))
+        renderer_from_project(project["renderer"])
+    except (ProjectError, lua_project.LuaError) as error:
+        pytest.skip("the Python reader does not take this project either: %s" % error)
+    check_project_file(host, path, tmp_path)
+
+
+@pytest.mark.gpu
+def test_cpp_renders_a_project_file(host, tmp_path):
+    """`pyrite project.lua` through the C++ layer: project file -> film -> render.png; the film equals the oracle's."""
+    import oracle
+    from pyrite_amd import lua_project
+
+    path = os.path.join(PROJECTS, "gallery.lua")
+    project, _ = flatten_with_python(path, str(tmp_path))
+    png, film_path = os.path.join(tmp_path, "render.png"), os.path.join(tmp_path, "film.bin")
+    out = subprocess.check_output([HOST_TOOL, "render-project", path, str(tmp_path), "5", png, film_path], text=True)
+    assert "The scene contains" in out and "Saving final result" in out
+    project, base_dir = lua_project.load_project(path)
+    world, cam, r, cpu_film = scenes.build(project, seed=5, base_dir=base_dir)
+    gpu = np.fromfile(film_path, dtype=np.float32).reshape(cpu_film.grains.shape)
+    oracle.OracleScene(world).render(r, cam, cpu_film, threads=4)
+    assert np.array_equal(gpu[..., 1], cpu_film.grains[..., 1])
+    a = np.divide(gpu[..., 0], gpu[..., 1], out=np.zeros_like(gpu[..., 0]), where=gpu[..., 1] > 0)
+    b = cpu_film.develop()
+    e = np.sqrt(((a - b) ** 2).sum(-1)) / (np.sqrt((b ** 2).sum(-1)) + 1e-6)
+    assert (e <= 1e-5).mean() >= 0.999
+    assert images.read_png(png).shape == (cpu_film.height, cpu_film.width, 3)
