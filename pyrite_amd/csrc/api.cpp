@@ -197,6 +197,7 @@ struct PyrScene {
     uint32_t* tail_count = nullptr; // device, kFeedBytes: the work-feed cursors of the intersect kernel
     // wavefront scheduler: path pool (grown on demand, kept between renders) and the pinned word the round loop polls
     DeviceBuffer wf_stage, wf_groups, wf_companions, wf_words;
+    DeviceBuffer tape; // spectral tape of the stage-scheduled kernel (grown on demand, kept between renders)
     uint32_t wf_slots = 0, wf_companion_rows = 0;
     uint32_t* wf_host_flag = nullptr;
     ~PyrScene() {
@@ -464,6 +465,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.num_nodes = (uint32_t)bvh.nodes.size();
     v.num_prims = (uint32_t)prims.size();
     v.num_spectra = d->num_spectra;
+    v.num_programs = d->num_programs;
     v.num_spectrum_floats = d->num_spectrum_floats;
     {
         const uint32_t floats = d->num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float)) + d->num_spectrum_floats;
@@ -598,6 +600,18 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     const char* steps = std::getenv("PYRITE_SM_STEPS");
     L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
+    if (L.scheduler == 1 && scene->dev.needs_interpreter == 0) {
+        L.tape_lanes = tape_lanes_bound(scene->num_cus);
+        L.tape_max_ops = tape_ops_bound(L);
+        const size_t bytes = (size_t)L.tape_lanes * L.tape_max_ops * sizeof(unsigned long long);
+        if (bytes > scene->tape.bytes) {
+            HIP_TRY(hipStreamSynchronize(stream)); // an earlier render of this scene may still be reading the old tape
+            scene->tape.release();
+            int rc = scene->tape.alloc(bytes);
+            if (rc != PYR_OK) return rc;
+        }
+        L.tape = (unsigned long long*)scene->tape.ptr;
+    }
     int rc = launch_render(scene->dev, L, count, stream, scene->num_cus);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());
     return PYR_OK;

@@ -89,6 +89,7 @@ struct DevScene {
     uint32_t needs_interpreter; // some program is neither a constant nor a fast shape
     uint32_t num_nodes, num_prims;
     uint32_t num_spectra, num_spectrum_floats;
+    uint32_t num_programs;
     uint32_t lds_table_floats; // > 0: the spectrum tables are staged into LDS (this many floats)
     // texture space (interpreter builds only)
     const float* tri_tex;          // DevTriTex[] by original triangle index, or nullptr
@@ -120,6 +121,11 @@ struct RenderLaunch {
     uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm), 2 = wavefront
     uint32_t sm_phase_lanes, sm_trav_steps; // stage scheduler: lanes that make a phase run; traversal steps per turn
     uint32_t stack_lds; // traversal stack levels kept in LDS (set by launch_render; deeper levels spill to scratch in the sm kernel)
+    // Spectral tape of the stage-scheduled kernel (kernels.hip "Spectral tape"): [tape_max_ops][tape_lanes] 8-byte records,
+    // one column per lane of the persistent grid.
+    unsigned long long* tape;
+    uint32_t tape_lanes, tape_max_ops;
+    uint32_t tape_programs_lds; // programs whose prepared form the kernel keeps in LDS for the replay (set by launch_render; 0 = none)
 };
 
 // Path pool of the wavefront scheduler (kernels.hip "Wavefront integrator"): n slots, all arrays [field][slot].
@@ -165,6 +171,8 @@ int launch_develop(const DevelopLaunch& launch, void* stream);
 
 // launchers (kernels.hip)
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);
+uint32_t tape_ops_bound(const RenderLaunch& launch); // records per path the stage-scheduled kernel may append to its spectral tape
+uint32_t tape_lanes_bound(int num_cus);              // lanes (tape columns) of the largest grid launch_render starts
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);
 // Wavefront render: alternates the logic and traversal kernels until every path of the launch has ended. Blocks on `stream`
 // (the loop's end is decided by the device). `host_flag` is one pinned host word.

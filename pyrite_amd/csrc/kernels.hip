@@ -1212,6 +1212,7 @@ DEV DevScene stage_tables(const DevScene& S, float* lds, uint32_t lds_floats_bef
 }
 
 // Start of render_tile's loop body (simple.rs:78-107) for iteration `iteration` of raster tile `tile`.
+template <bool COMPANION_STATE = true>
 DEV void start_sample(const RenderLaunch& L, uint32_t tile, uint64_t iteration, const TileArea& area, Path& p, Spectral& spec) {
     const uint32_t SS = L.spectrum_samples;
     p.rng = rng_seed(L.seed, tile, iteration);
@@ -1245,10 +1246,11 @@ DEV void start_sample(const RenderLaunch& L, uint32_t tile, uint64_t iteration, 
         uint32_t hero = rng_range_usize(p.rng, SS);
         p.wl = spec.wl(hero);
         spec.wl(hero) = spec.wl(SS - 1);
-        for (uint32_t k = 0; k + 1 < SS; ++k) {
-            spec.bright(k) = 0.0f;
-            spec.refl(k) = 1.0f;
-        }
+        if constexpr (COMPANION_STATE)
+            for (uint32_t k = 0; k + 1 < SS; ++k) {
+                spec.bright(k) = 0.0f;
+                spec.refl(k) = 1.0f;
+            }
     }
     p.bright = 0.0f;
     p.refl = 1.0f;
@@ -1833,9 +1835,49 @@ DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Count
 
 // Per-path state of the resumable integrator and the code of its phases; shared by the stage-scheduled kernel (state in
 // registers) and the wavefront kernels (state in HBM between phases).
-template <bool COUNT, bool INTERP>
+// Spectral tape (TAPE builds: the stage-scheduled kernel on scenes without interpreter programs, i.e. every BASELINE
+// config). Without the interpreter a colour program is a function of the wavelength alone, and nothing a path decides
+// depends on its brightness or reflectance (the reference has no Russian roulette; only the hero wavelength's value enters
+// the geometry, through dispersion). So `contribute` (renderer/algorithm.rs:14-100) need not run while the path is walked,
+// in phases that execute at a third of the wave's width: each path only records what contribute would be applied to --
+//     MUL   program, s   reflectance *= program(wl) * s        a bounce (algorithm.rs:48-63)
+//     ADD   program, s   brightness  += program(wl) * s * reflectance   emission, sky, an unblocked light sample (:30-46, :65-90)
+//     SCALE s            reflectance *= s                      the BRDF factor (:92-98)
+// -- 8 bytes per record, appended to the lane's column of a tape in HBM, and when paths end the wave replays the tapes of all
+// its finished lanes with one (path, wavelength) pair per lane, at full width: the same f32 operations in the same order for
+// every wavelength, so the film is bit-identical. The S wavelengths stay in LDS; the per-lane brightness / reflectance arrays
+// ([2 (S - 1)][256] floats of LDS) are gone, which lets the traversal stack live in LDS down to 16 levels.
+constexpr uint32_t kTapeEagerSlots = 8; // LDS rows for the values of the programs that read a spectrum (replay_tapes)
+constexpr uint32_t TAPE_MUL = 0u, TAPE_ADD = 1u, TAPE_SCALE = 2u, TAPE_HERO_ONLY = 1u << 29, TAPE_CONSTANT = 1u << 28, TAPE_PROGRAM_MASK = (1u << 28) - 1u;
+
+template <bool COUNT, bool INTERP, bool TAPE = false>
 struct Walker {
     uint32_t stage = ST_NEW;
+    uint32_t n_ops = 0; // TAPE: records on this path's tape
+    const uint32_t* tape_prepared = nullptr; // TAPE, eager replay: the kernel's LDS table of prepared programs, else nullptr
+    DEV void tape_push(const RenderLaunch& L, uint32_t kind, uint32_t program, float s, bool hero_only = false) {
+#ifndef PYR_TAPE_NOSTORE
+        if (n_ops < L.tape_max_ops)
+#else
+        if (n_ops > 1000000u)
+#endif
+        {
+            uint32_t word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | (program & TAPE_PROGRAM_MASK);
+            if (tape_prepared != nullptr && kind != TAPE_SCALE) {
+                // eager replay: the record names the LDS slot of the program's value; a constant program is folded into the
+                // factor -- c * s is the very product `contribute` forms (program value times probability)
+                const uint32_t* e = tape_prepared + 8 * program;
+                if (e[0] == 0u) {
+                    word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | TAPE_CONSTANT;
+                    s = __uint_as_float(e[1]) * s;
+                } else {
+                    word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | e[7];
+                }
+            }
+            L.tape[(size_t)n_ops * L.tape_lanes + (blockIdx.x * BLOCK + threadIdx.x)] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
+        }
+        n_ops++;
+    }
     uint32_t chunk = 0; // next chunk of this lane's sample sequence (chunk_begin + wave, + total_waves, ...)
     Path p{};
     Trav t{};
@@ -1858,10 +1900,14 @@ struct Walker {
         const uint32_t n_add = L.spectrum_samples - 1;
         if (b_has_brdf) {
             const float brdf = 2.0f * fabsf(dot(b_out, b_normal));
-            p.refl *= brdf;
-            if (p.use_additional) {
-                for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
-                touched |= TOUCH_REFL;
+            if constexpr (TAPE) {
+                tape_push(L, TAPE_SCALE, 0u, brdf);
+            } else {
+                p.refl *= brdf;
+                if (p.use_additional) {
+                    for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
+                    touched |= TOUCH_REFL;
+                }
             }
         }
         p.o = b_position;
@@ -1878,7 +1924,7 @@ struct Walker {
     // EXPOSE / NEW: finish the path (simple.rs:133-139) and start the next sample of this lane's sequence (simple.rs:78-107)
     DEV void expose_and_restart(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt, uint32_t lane, uint32_t total_waves) {
         if (stage == ST_EXPOSE) {
-            finish_path<COUNT>(L, p, spec, cnt);
+            if constexpr (!TAPE) finish_path<COUNT>(L, p, spec, cnt); // TAPE: the wave has replayed this lane's tape (replay_tapes)
             stage = ST_NEW;
         }
         if (stage == ST_NEW) {
@@ -1890,7 +1936,8 @@ struct Walker {
                 const bool ok = locate_chunk(L, chunk, lane, tile, iteration, area);
                 chunk += total_waves;
                 if (ok) {
-                    start_sample(L, tile, iteration, area, p, spec);
+                    start_sample<!TAPE>(L, tile, iteration, area, p, spec);
+                    n_ops = 0;
                     touched |= TOUCH_NEW | TOUCH_BRIGHT | TOUCH_REFL;
                     if (COUNT) cnt.samples++;
                     if (L.bounces == 0) {
@@ -1922,14 +1969,18 @@ struct Walker {
                     }
                 }
             }
-            const Prepared q_prog = prepare_program<INTERP>(S, color);
-            VmInput in{p.wl, -ray_d, ray_d};
-            p.bright += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * p.refl;
-            if (p.use_additional)
-                for (uint32_t k = 0; k < n_add; ++k) {
-                    in.wavelength = spec.wl(k);
-                    spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * spec.refl(k);
-                }
+            if constexpr (TAPE) {
+                tape_push(L, TAPE_ADD, color, 1.0f);
+            } else {
+                const Prepared q_prog = prepare_program<INTERP>(S, color);
+                VmInput in{p.wl, -ray_d, ray_d};
+                p.bright += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * p.refl;
+                if (p.use_additional)
+                    for (uint32_t k = 0; k < n_add; ++k) {
+                        in.wavelength = spec.wl(k);
+                        spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * 1.0f * spec.refl(k);
+                    }
+            }
             stage = ST_EXPOSE;
             return;
         }
@@ -1955,14 +2006,18 @@ struct Walker {
         if (comp.bsdf == PYR_BSDF_EMISSIVE) {
             if (p.sample_light) {
                 p.use_additional = !normal_dispersed && p.use_additional;
-                const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
-                VmInput in{p.wl, normal, ray_d, tx, ty};
-                p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
-                if (p.use_additional)
-                    for (uint32_t k = 0; k < n_add; ++k) {
-                        in.wavelength = spec.wl(k);
-                        spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * component_probability * spec.refl(k);
-                    }
+                if constexpr (TAPE) {
+                    tape_push(L, TAPE_ADD, comp.color_program, component_probability);
+                } else {
+                    const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
+                    VmInput in{p.wl, normal, ray_d, tx, ty};
+                    p.bright += eval_prepared<INTERP>(S, q_prog, in) * component_probability * p.refl;
+                    if (p.use_additional)
+                        for (uint32_t k = 0; k < n_add; ++k) {
+                            in.wavelength = spec.wl(k);
+                            spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * component_probability * spec.refl(k);
+                        }
+                }
             }
             stage = ST_EXPOSE;
             return;
@@ -1990,7 +2045,9 @@ struct Walker {
         }
         const float bounce_probability = scatter_probability * component_probability;
         p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
-        {
+        if constexpr (TAPE) {
+            tape_push(L, TAPE_MUL, comp.color_program, bounce_probability);
+        } else {
             const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
             VmInput in{p.wl, normal, ray_d, tx, ty};
             p.refl *= eval_prepared<INTERP>(S, q_prog, in) * bounce_probability;
@@ -2055,14 +2112,18 @@ struct Walker {
                 }
                 const float l_probability = ls_scale * material_probability;
                 touched |= TOUCH_BRIGHT;
-                const Prepared q_prog = prepare_program<INTERP>(S, l_color);
-                VmInput in{p.wl, target_normal, t.d, ls_physical ? ls_tx : 0.0f, ls_physical ? ls_ty : 0.0f};
-                p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
-                if (p.use_additional && !l_dispersed)
-                    for (uint32_t k = 0; k < n_add; ++k) {
-                        in.wavelength = spec.wl(k);
-                        spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
-                    }
+                if constexpr (TAPE) {
+                    tape_push(L, TAPE_ADD, l_color, l_probability, l_dispersed);
+                } else {
+                    const Prepared q_prog = prepare_program<INTERP>(S, l_color);
+                    VmInput in{p.wl, target_normal, t.d, ls_physical ? ls_tx : 0.0f, ls_physical ? ls_ty : 0.0f};
+                    p.bright += eval_prepared<INTERP>(S, q_prog, in) * l_probability * p.refl;
+                    if (p.use_additional && !l_dispersed)
+                        for (uint32_t k = 0; k < n_add; ++k) {
+                            in.wavelength = spec.wl(k);
+                            spec.bright(k) += eval_prepared<INTERP>(S, q_prog, in) * l_probability * spec.refl(k);
+                        }
+                }
             }
         }
         const DevLamp& lamp = S.lamps[nee_lamp];
@@ -2089,16 +2150,141 @@ struct Walker {
     }
 };
 
+// Replays the tapes of the wave's finished lanes (`exposing`) and exposes the film: contribute + Film::expose for every
+// (path, wavelength) pair, one pair per lane. Item i of the wave is wavelength i % S of the (i / S)-th finished lane; index
+// S - 1 stands for the hero (kept in the lane's registers), 0 .. S - 2 for the companions in LDS. A path that dispersed
+// exposes its hero only (simple.rs:133-139); a light sample whose material reads the wavelength is added for the hero only
+// (algorithm.rs:78). Consecutive records of one program (the light samples of one estimation) share one look-up, as in the
+// synchronous walk. Must be called by every lane of the wave.
+template <bool COUNT>
+DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, const Path& p, const float* wave_wl, uint32_t* wave_list,
+                      const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long mask = __ballot(exposing);
+    const uint32_t n = (uint32_t)__popcll(mask);
+    if (n == 0) return;
+#ifdef PYR_TAPE_NOREPLAY
+    if (n_ops < 1000000u) return;
+#endif
+    if (exposing) wave_list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t SS = L.spectrum_samples, items = n * SS;
+    // Longest tape among the finished lanes. The wave reads the tape row by row: a row (one record index of all 64 lanes) is 512
+    // contiguous bytes, so every lane loads its own column's record -- one coalesced load per row, eight rows in flight -- and
+    // an item takes the record of the lane it replays with a cross-lane read. (Reading record after record of one column from
+    // the item's lane was a chain of dependent HBM round trips: it took a quarter of the render.)
+    uint32_t max_ops = exposing ? (n_ops < L.tape_max_ops ? n_ops : L.tape_max_ops) : 0u;
+    for (int off = 32; off > 0; off >>= 1) max_ops = max(max_ops, (uint32_t)__shfl_xor((int)max_ops, off));
+    const unsigned long long* my_column = L.tape + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    constexpr uint32_t ROWS = 8;
+    for (uint32_t base = 0; base < items; base += 64) {
+        const uint32_t i = base + lane;
+        const bool active = i < items;
+        const uint32_t rank = active ? i / SS : 0u, k = active ? i - rank * SS : 0u;
+        const uint32_t src = wave_list[rank];
+        const uint32_t ops = (uint32_t)__shfl((int)n_ops, (int)src);
+        const float px = __shfl(p.px, (int)src), py = __shfl(p.py, (int)src), hero_wl = __shfl(p.wl, (int)src);
+        const bool use_additional = __shfl((int)p.use_additional, (int)src) != 0;
+        const bool hero = k == SS - 1;
+        const bool run = active && (hero || use_additional);
+        const float wl = hero ? hero_wl : wave_wl[k * BLOCK + src];
+        float refl = 1.0f, bright = 0.0f, value = 0.0f;
+        uint32_t value_of = 0xFFFFFFFFu;
+        // A scene has few programs that read a spectrum (C3: three wall colours and the lamp). When they fit the LDS rows
+        // reserved for them, each is looked up once per item, here, in uniform control flow -- the records below then only pick
+        // the value (and apply the program's constant factor, the same multiplication run_program makes).
+        const bool eager = n_spectral != 0;
+        if (eager) {
+            const uint32_t* slot_program = prepared_lds + 8 * L.tape_programs_lds;
+            for (uint32_t slot = 0; slot < n_spectral; ++slot) {
+                const uint32_t* e = prepared_lds + 8 * slot_program[slot];
+                Prepared q_prog;
+                q_prog.mode = e[0], q_prog.c = __uint_as_float(e[1]);
+                q_prog.sp.format = e[2], q_prog.sp.min = __uint_as_float(e[3]), q_prog.sp.max = __uint_as_float(e[4]), q_prog.sp.offset = e[5], q_prog.sp.count = e[6];
+                q_prog.data = S.spectrum_data + e[5];
+                q_prog.id = slot_program[slot];
+                VmInput in{wl, mk(0, 0, 0), mk(0, 0, 0)};
+                spectral_values[slot * BLOCK] = eval_prepared<false>(S, q_prog, in);
+            }
+        }
+        for (uint32_t r0 = 0; r0 < max_ops; r0 += ROWS) {
+            unsigned long long rows[ROWS];
+#pragma unroll
+            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < max_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
+#pragma unroll
+            for (uint32_t j = 0; j < ROWS; ++j) {
+                const uint32_t word = (uint32_t)__shfl((int)(uint32_t)rows[j], (int)src);
+                const float s = __uint_as_float((uint32_t)__shfl((int)(uint32_t)(rows[j] >> 32), (int)src));
+                if (!run || r0 + j >= ops) continue;
+                const uint32_t kind = word >> 30;
+                if (kind == TAPE_SCALE) {
+                    refl *= s;
+                    continue;
+                }
+                if ((word & TAPE_HERO_ONLY) && !hero) continue;
+                const uint32_t program = word & TAPE_PROGRAM_MASK;
+                if (eager) { // the factor is s itself (constant program, folded when recorded) or the slot's value times s
+                    const float vs = (word & TAPE_CONSTANT) ? s : spectral_values[program * BLOCK] * s;
+                    if (kind == TAPE_MUL)
+                        refl *= vs;
+                    else
+                        bright += vs * refl;
+                    continue;
+                }
+                if (program != value_of) {
+#ifdef PYR_REPLAY_NOEVAL
+                    value = 1.0f;
+#else
+                    // the prepared form of a program: from the LDS table when the kernel staged one (a replay item changes
+                    // program with nearly every record; fetching the program record from HBM each time was 16 % of the render)
+                    Prepared q_prog;
+                    if (program < L.tape_programs_lds) {
+                        const uint32_t* e = prepared_lds + 8 * program;
+                        q_prog.mode = e[0];
+                        q_prog.c = __uint_as_float(e[1]);
+                        q_prog.sp.format = e[2];
+                        q_prog.sp.min = __uint_as_float(e[3]);
+                        q_prog.sp.max = __uint_as_float(e[4]);
+                        q_prog.sp.offset = e[5];
+                        q_prog.sp.count = e[6];
+                        q_prog.data = S.spectrum_data + e[5];
+                        q_prog.id = program;
+                    } else {
+                        q_prog = prepare_program<false>(S, program);
+                    }
+                    VmInput in{wl, mk(0, 0, 0), mk(0, 0, 0)};
+                    value = eval_prepared<false>(S, q_prog, in);
+#endif
+                    value_of = program;
+                }
+                if (kind == TAPE_MUL)
+                    refl *= value * s;
+                else
+                    bright += value * s * refl;
+            }
+        }
+#ifdef PYR_REPLAY_NOEXPOSE
+        if (run && bright == 123.456f) expose_grain<COUNT>(L, film_pixel_base(L, px, py), wl, bright, cnt);
+#else
+        if (run) expose_grain<COUNT>(L, film_pixel_base(L, px, py), wl, bright, cnt);
+#endif
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
+    constexpr bool TAPE = !INTERP; // see "Spectral tape"
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
+    // LDS rows of 256 floats: TAPE: S wavelengths + one row of per-wave lane lists; else wavelengths / brightness / reflectance
+    const uint32_t spectral_rows = TAPE ? SS + 1 + kTapeEagerSlots : 3 * SS;
     TravStack stack;
-    stack.lds = reinterpret_cast<int*>(lds + 3 * SS * BLOCK) + threadIdx.x;
+    stack.lds = reinterpret_cast<int*>(lds + spectral_rows * BLOCK) + threadIdx.x;
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
-    const uint32_t lds_base_floats = (3 * SS + L.stack_lds) * BLOCK;
+    const uint32_t lds_base_floats = (spectral_rows + L.stack_lds) * BLOCK;
     const SceneView view = stage_scene<LDS_SCENE>(S0, lds, lds_base_floats, true);
     const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0));
 
@@ -2106,8 +2292,32 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
     const uint32_t waves_per_block = BLOCK / 64;
     const uint32_t total_waves = gridDim.x * waves_per_block;
     const int phase_lanes = (int)L.sm_phase_lanes, trav_steps = (int)L.sm_trav_steps;
-    Walker<COUNT, INTERP> w;
+    Walker<COUNT, INTERP, TAPE> w;
     w.chunk = L.chunk_begin + blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    w.tape_prepared = nullptr;
+    const float* wave_wl = lds + (threadIdx.x & ~63u);
+    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
+    // prepared programs for the replay: 8 words each, behind everything else in LDS
+    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0) + (LDS_TABLES ? S0.lds_table_floats : 0));
+    // programs that read a spectrum get a slot (their rank among such programs); the slot -> program list follows the table
+    uint32_t n_spectral = 0;
+    float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+    if constexpr (TAPE) {
+        auto reads_spectrum = [&](uint32_t i) { return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && S0.programs[i].fast != FAST_NONE; };
+        for (uint32_t i = 0; i < L.tape_programs_lds; ++i) n_spectral += reads_spectrum(i) ? 1u : 0u;
+        for (uint32_t i = threadIdx.x; i < L.tape_programs_lds; i += BLOCK) {
+            const Prepared q = prepare_program<false>(S, i);
+            uint32_t slot = 0;
+            for (uint32_t j = 0; j < i; ++j) slot += reads_spectrum(j) ? 1u : 0u;
+            uint32_t* e = prepared_lds + 8 * i;
+            e[0] = q.mode, e[1] = __float_as_uint(q.c), e[2] = q.sp.format, e[3] = __float_as_uint(q.sp.min), e[4] = __float_as_uint(q.sp.max);
+            e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = slot;
+            if (reads_spectrum(i) && slot < kTapeEagerSlots) prepared_lds[8 * L.tape_programs_lds + slot] = i;
+        }
+        __syncthreads();
+        if (n_spectral > kTapeEagerSlots) n_spectral = 0; // too many for the reserved rows: the replay looks them up record by record
+        if (n_spectral != 0) w.tape_prepared = prepared_lds;
+    }
 
     PROF_DECL;
     for (;;) {
@@ -2121,6 +2331,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
 
         if (nE >= phase_lanes || nE == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
+            if constexpr (TAPE) replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
             w.expose_and_restart(S, L, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
@@ -2589,10 +2800,19 @@ static uint32_t short_stack_levels(const DevScene& scene, size_t other_bytes, ui
     }
     return std::max(1u, std::min(levels, scene.wide_nodes ? scene.wide_stack_depth : scene.stack_depth));
 }
+// Records a path can append: one MUL and one SCALE per bounce, light_samples ADDs in each of the two next-event estimations
+// (tracer.rs:257), one closing ADD (emission or sky).
+uint32_t tape_ops_bound(const RenderLaunch& launch) { return 2u * launch.bounces + 2u * launch.light_samples + 1u; }
+uint32_t tape_lanes_bound(int num_cus) { return (uint32_t)num_cus * 8u * BLOCK; } // launch_render never starts more than 8 blocks per CU
+constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for the replay (4 KB); scenes with more use the HBM records
+static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_programs <= kTapeProgramsLds ? scene.num_programs : 0u; }
+static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return launch.scheduler == 1 && scene.needs_interpreter == 0; }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
-    size_t bytes = (size_t)(3 * launch.spectrum_samples + launch.stack_lds) * BLOCK * sizeof(float);
+    const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
+    size_t bytes = (spectral_rows + launch.stack_lds) * BLOCK * sizeof(float);
     if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
     bytes += (size_t)scene.lds_table_floats * sizeof(float);
+    if (uses_tape(scene, launch)) bytes += ((size_t)tape_programs_in_lds(scene) * 8 + kTapeEagerSlots) * sizeof(uint32_t);
     return bytes;
 }
 
@@ -2620,6 +2840,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     }
     RenderLaunch launch = launch_in;
     launch.stack_lds = 0;
+    launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernel is built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
     launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), 4) : scene.stack_depth;
     const size_t lds = render_lds_bytes(scene, launch);
@@ -2648,6 +2869,10 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
     uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (grid > blocks_needed) grid = blocks_needed;
+    if (uses_tape(scene, launch) && (launch.tape == nullptr || (size_t)grid * BLOCK > launch.tape_lanes || launch.tape_max_ops < tape_ops_bound(launch))) {
+        g_kernel_error = "the spectral tape is missing or too small for this launch";
+        return PYR_ERR_INVALID_ARGUMENT;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
     err = hipGetLastError();
     if (err != hipSuccess) {
