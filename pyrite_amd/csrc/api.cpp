@@ -600,6 +600,8 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     const char* steps = std::getenv("PYRITE_SM_STEPS");
     L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
+    const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
+    L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;
     if (L.scheduler == 1 && scene->dev.needs_interpreter == 0) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
         L.tape_max_ops = tape_ops_bound(L);

@@ -2292,6 +2292,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
     const uint32_t waves_per_block = BLOCK / 64;
     const uint32_t total_waves = gridDim.x * waves_per_block;
     const int phase_lanes = (int)L.sm_phase_lanes, trav_steps = (int)L.sm_trav_steps;
+    const int expose_lanes = TAPE ? (int)L.sm_expose_lanes : phase_lanes; // the replay works at full width whatever the count, but has a fixed cost per turn
     Walker<COUNT, INTERP, TAPE> w;
     w.chunk = L.chunk_begin + blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     w.tape_prepared = nullptr;
@@ -2329,7 +2330,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, Render
         int nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
         if (max(max(nT, nS), max(nN, nE)) == 0) break; // every lane is DONE
 
-        if (nE >= phase_lanes || nE == max(max(nT, nS), max(nN, nE))) {
+        if (nE >= expose_lanes || nE == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             if constexpr (TAPE) replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
             w.expose_and_restart(S, L, spec, cnt, lane, total_waves);
