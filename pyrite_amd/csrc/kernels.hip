@@ -36,6 +36,9 @@ const char* kernels_last_error() { return g_kernel_error.c_str(); }
 #define DEV __device__ __forceinline__
 
 constexpr int BLOCK = 256;
+#ifndef PYR_SM_WAVES
+#define PYR_SM_WAVES 4 // waves per SIMD (= workgroups per CU) the stage-scheduled kernel is built for
+#endif
 constexpr float DIST_EPSILON = 0.0001f; // math.rs:4
 constexpr float PI_F = 3.14159265358979323846f;
 #define PYR_INF __builtin_huge_valf()
@@ -2273,7 +2276,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 }
 
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
-__global__ __launch_bounds__(BLOCK, 4) void render_kernel_sm(DevScene S0, RenderLaunch L) {
+__global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     constexpr bool TAPE = !INTERP; // see "Spectral tape"
     const uint32_t SS = L.spectrum_samples;
@@ -2843,7 +2846,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.stack_lds = 0;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernel is built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
-    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), 4) : scene.stack_depth;
+    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), PYR_SM_WAVES) : scene.stack_depth;
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
