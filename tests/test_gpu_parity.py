@@ -346,3 +346,51 @@ def test_full_size_c2_properties(gpu_lib):
     gpu = r.new_film(1024, 1024)
     r.render(gpu, cam, world, tile_range=(32 * 16 + 14, 32 * 16 + 18))
     assert_parity(gpu, cpu)
+
+
+# ------------------------------------------------------------------------------------------------ spectral tape (stage scheduler)
+def _many_materials_scene(n_spheres, spectral, width=48, height=32, pixel_samples=8):
+    """A floor, a lamp and `n_spheres` small spheres, each with a material of its own: `spectral` -> every colour is its own
+    array spectrum (more spectrum-reading programs than the replay keeps values for), else its own constant."""
+    from pyrite_amd.project import camera, light_source, material, shape, spectrum, transform, vector
+
+    rng = np.random.RandomState(11)
+    objects = [
+        shape.sphere(position=vector(0, 0, -100), radius=100.0, material={"surface": material.diffuse(color=0.7)}),
+        shape.sphere(position=vector(0, 0, 6), radius=1.0, material={"surface": material.emissive(color=light_source.d65 * 5)}),
+    ]
+    side = int(np.ceil(np.sqrt(n_spheres)))
+    for i in range(n_spheres):
+        x, y = (i % side) - side / 2 + 0.5, (i // side) - side / 2 + 0.5
+        if spectral:
+            colour = spectrum(format="array", min=380.0, max=780.0, points=[float(v) for v in rng.uniform(0.1, 0.9, 7)])
+        else:
+            colour = float(rng.uniform(0.1, 0.9))
+        objects.append(shape.sphere(position=vector(x * 0.8, y * 0.8, 0.3), radius=0.3, material={"surface": material.diffuse(color=colour)}))
+    return {
+        "image": {"width": width, "height": height},
+        "renderer": renderer.simple(pixel_samples=pixel_samples, light_samples=2, bounces=5, tile_size=16, spectrum_samples=5),
+        "camera": camera.perspective(fov=60, transform=transform.look_at(**{"from": vector(0, -7, 4), "to": vector(0, 0, 0.3), "up": vector(z=1)})),
+        "world": {"sky": light_source.d65 * 0.3, "objects": objects},
+    }
+
+
+@pytest.mark.parametrize("n_spheres,spectral", [(12, True), (150, False), (150, True)])
+def test_tape_replay_fallbacks_match_the_oracle(n_spheres, spectral, gpu_lib, monkeypatch):
+    """The stage scheduler's spectral tape: more than 8 spectrum-reading programs (values looked up record by record from the
+    LDS table of prepared programs), more than 128 programs (prepared from the HBM records), and both at once."""
+    monkeypatch.setenv("PYRITE_SCHEDULER", "sm")
+    gfilm, cfilm, gcount, ccount = render_both(_many_materials_scene(n_spheres, spectral), 4, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    assert gcount["exposures"] == ccount["exposures"] and gcount["shadow_rays"] == ccount["shadow_rays"]
+
+
+def test_tape_records_the_bound_and_no_more(gpu_lib, monkeypatch):
+    """A path appends at most 2 * bounces + 2 * light_samples + 1 records: a closed, all-diffuse box with an inner lamp and
+    the maximum next-event work makes the longest tapes; one bounce and no light samples the shortest."""
+    monkeypatch.setenv("PYRITE_SCHEDULER", "sm")
+    for bounces, light_samples in ((12, 6), (1, 0), (2, 1)):
+        project = scenes.c2_cornell(40, 40, 6)
+        project["renderer"] = renderer.simple(pixel_samples=6, bounces=bounces, light_samples=light_samples, tile_size=16)
+        gfilm, cfilm, _, _ = render_both(project, 9, gpu_lib)
+        assert_parity(gfilm, cfilm)
