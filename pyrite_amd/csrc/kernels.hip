@@ -2214,10 +2214,40 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
             unsigned long long rows[ROWS];
 #pragma unroll
             for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < max_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
+            // all cross-lane reads of the batch first (one wait), then, in the eager form, all value reads (one more)
+            uint32_t words[ROWS];
+            float factors[ROWS];
 #pragma unroll
             for (uint32_t j = 0; j < ROWS; ++j) {
-                const uint32_t word = (uint32_t)__shfl((int)(uint32_t)rows[j], (int)src);
-                const float s = __uint_as_float((uint32_t)__shfl((int)(uint32_t)(rows[j] >> 32), (int)src));
+                words[j] = (uint32_t)__shfl((int)(uint32_t)rows[j], (int)src);
+                factors[j] = __uint_as_float((uint32_t)__shfl((int)(uint32_t)(rows[j] >> 32), (int)src));
+            }
+            if (eager) { // the factor is s itself (constant program, folded when recorded) or the slot's value times s
+                float vs[ROWS];
+#pragma unroll
+                for (uint32_t j = 0; j < ROWS; ++j) {
+                    const uint32_t slot = words[j] & (kTapeEagerSlots - 1u); // SCALE records carry slot 0: a harmless read
+                    vs[j] = (words[j] & TAPE_CONSTANT) ? factors[j] : spectral_values[slot * BLOCK] * factors[j];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < ROWS; ++j) {
+                    if (!run || r0 + j >= ops) continue;
+                    const uint32_t kind = words[j] >> 30;
+                    if (kind == TAPE_SCALE)
+                        refl *= factors[j];
+                    else if (!(words[j] & TAPE_HERO_ONLY) || hero) {
+                        if (kind == TAPE_MUL)
+                            refl *= vs[j];
+                        else
+                            bright += vs[j] * refl;
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < ROWS; ++j) {
+                const uint32_t word = words[j];
+                const float s = factors[j];
                 if (!run || r0 + j >= ops) continue;
                 const uint32_t kind = word >> 30;
                 if (kind == TAPE_SCALE) {
@@ -2226,14 +2256,6 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 }
                 if ((word & TAPE_HERO_ONLY) && !hero) continue;
                 const uint32_t program = word & TAPE_PROGRAM_MASK;
-                if (eager) { // the factor is s itself (constant program, folded when recorded) or the slot's value times s
-                    const float vs = (word & TAPE_CONSTANT) ? s : spectral_values[program * BLOCK] * s;
-                    if (kind == TAPE_MUL)
-                        refl *= vs;
-                    else
-                        bright += vs * refl;
-                    continue;
-                }
                 if (program != value_of) {
 #ifdef PYR_REPLAY_NOEVAL
                     value = 1.0f;
