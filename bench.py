@@ -161,6 +161,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    if world_size > 1:
+        # bring up the communicator and the point-to-point channels the gather uses before anything is timed (RCCL creates
+        # them lazily at the first collective of each kind): one tiny gather, the same call the step makes
+        probe = torch.zeros(16, dtype=torch.float32, device="cpu" if rehearsal else device)
+        dist.gather(probe, [torch.empty_like(probe) for _ in range(world_size)] if rank == 0 else None, dst=0)
+        if not rehearsal:
+            torch.cuda.synchronize(device)
+
     builder, width, height, spp = WORKLOADS[args.workload]
     reduced = (args.spp is not None and args.spp != spp) or rehearsal
     spp = args.spp or spp
