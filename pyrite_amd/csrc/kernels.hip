@@ -1850,6 +1850,9 @@ DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Count
 // its finished lanes with one (path, wavelength) pair per lane, at full width: the same f32 operations in the same order for
 // every wavelength, so the film is bit-identical. The S wavelengths stay in LDS; the per-lane brightness / reflectance arrays
 // ([2 (S - 1)][256] floats of LDS) are gone, which lets the traversal stack live in LDS down to 16 levels.
+// Developer builds that time the parts of this scheme by leaving one out (the FILM IS WRONG under each of them; DESIGN.md 3.2
+// quotes the numbers): -DPYR_TAPE_NOSTORE (no records written), -DPYR_TAPE_NOREPLAY (no replay), -DPYR_REPLAY_NOEVAL (record
+// by record path: programs evaluate to 1), -DPYR_REPLAY_NOEXPOSE (no film atomics).
 constexpr uint32_t kTapeEagerSlots = 8; // LDS rows for the values of the programs that read a spectrum (replay_tapes)
 constexpr uint32_t TAPE_MUL = 0u, TAPE_ADD = 1u, TAPE_SCALE = 2u, TAPE_HERO_ONLY = 1u << 29, TAPE_CONSTANT = 1u << 28, TAPE_PROGRAM_MASK = (1u << 28) - 1u;
 
