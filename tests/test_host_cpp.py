@@ -256,3 +256,36 @@ def test_cpp_renders_a_project_file(host, tmp_path):
     e = np.sqrt(((a - b) ** 2).sum(-1)) / (np.sqrt((b ** 2).sum(-1)) + 1e-6)
     assert (e <= 1e-5).mean() >= 0.999
     assert images.read_png(png).shape == (cpu_film.height, cpu_film.width, 3)
+
+
+@pytest.mark.gpu
+def test_cpp_development_with_filter_and_white_balance(host, tmp_path):
+    """image.filter / image.white (main.rs:190-238): the C++ layer evaluates the two programs at the sampling wavelengths and
+    develops on the GPU; its PNG equals the Python front-end's development of the same film (cornell.lua's white = blackbody)."""
+    from pyrite_amd import develop, lua_project
+    from pyrite_amd.film import Film
+
+    path = os.path.join(tmp_path, "balanced.lua")
+    with open(path, "w") as f:
+        f.write("""
+local warm = spectrum {format = "curve", points = {{380, 0.2}, {500, 0.6}, {650, 1.0}, {780, 0.9}}}
+return {
+    image = {width = 40, height = 24, white = blackbody(4000), filter = warm * 0.9 + 0.05},
+    renderer = renderer.simple {pixel_samples = 8, tile_size = 16},
+    camera = camera.perspective {fov = 50, transform = transform.look_at {from = vector(0, 2, 8), to = vector(0, 1, 0)}},
+    world = {sky = light_source.d65 * 0.5, objects = {
+        shape.sphere {position = vector(0, -100, 0), radius = 100, material = {surface = material.diffuse {color = 0.6}}},
+        shape.sphere {position = vector(0, 1, 0), radius = 1, material = {surface = material.diffuse {color = rgb(0.9, 0.4, 0.2)}}},
+        shape.sphere {position = vector(2, 3, 2), radius = 0.5, material = {surface = material.emissive {color = light_source.a * 6}}},
+    }},
+}
+""")
+    png, film_path = os.path.join(tmp_path, "out.png"), os.path.join(tmp_path, "film.bin")
+    subprocess.check_call([HOST_TOOL, "render-project", path, "-", "2", png, film_path], stdout=subprocess.DEVNULL)
+    project, _ = lua_project.load_project(path)
+    film = Film(40, 24, 64, (380.0, 780.0))
+    film.grains[...] = np.fromfile(film_path, dtype=np.float32).reshape(film.grains.shape)
+    want = develop.develop(film, filter=project["image"]["filter"], white=project["image"]["white"])
+    got = images.read_png(png)
+    assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got == want).mean() > 0.99
+    assert got.std() > 5  # an image, not a constant
