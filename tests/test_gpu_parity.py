@@ -394,3 +394,30 @@ def test_tape_records_the_bound_and_no_more(gpu_lib, monkeypatch):
         project["renderer"] = renderer.simple(pixel_samples=6, bounces=bounces, light_samples=light_samples, tile_size=16)
         gfilm, cfilm, _, _ = render_both(project, 9, gpu_lib)
         assert_parity(gfilm, cfilm)
+
+
+def test_full_size_c3_properties(gpu_lib):
+    """BASELINE.json's C3 at full size on the stage scheduler with the spectral tape (819,212 triangles, 1920 x 1080, the
+    persistent grid at its full width), 2 spp: every sample exposes its wavelengths exactly once; the image rendered in one
+    launch equals the image rendered band by band into row windows the way an 8-rank cyclic plan renders it (pyrite_amd/
+    distributed.py) -- weights exactly, spectra up to the order of the float atomics."""
+    from pyrite_amd import distributed as pdist
+
+    W, H, spp = 1920, 1080, 2
+    world, cam, r, whole = scenes.build(scenes.c3_mesh_in_box(W, H, spp), seed=2)
+    c = r.render(whole, cam, world, counters=True)
+    assert c["samples"] == W * H * spp and c["triangle_tests"] > 0
+    weight = whole.grains[..., 1].sum(dtype=np.float64)
+    assert c["exposures"] == weight <= W * H * spp * r.spectrum_samples and weight >= 0.9999 * W * H * spp * r.spectrum_samples
+    assert not np.isnan(whole.grains).any()
+
+    shares = pdist.plan(W, H, r.tile_size, 8, "cyclic")
+    film = r.new_film(W, H)
+    for share in shares:
+        for tile_range, (first_row, rows) in share:
+            window = np.zeros((rows, W, r.spectrum_bins, 2), dtype=np.float32)
+            r.render(film, cam, world, tile_range=tile_range, film_rows=(first_row, rows), window=window)
+            film.grains[first_row:first_row + rows] += window
+    assert np.array_equal(film.grains[..., 1], whole.grains[..., 1])
+    assert np.allclose(film.grains[..., 0], whole.grains[..., 0], rtol=1e-4, atol=1e-6)
+    world.close()
