@@ -255,6 +255,8 @@ class World { // world.rs:31-36
     static std::unique_ptr<World> from_project(const WorldProject& world, const std::string& base_dir = ".");
     ~World();
     PyrScene* scene(int device = 0); // created on first use (BVH build + upload)
+    // World::intersect (world.rs:273-299) for a batch of rays, [n][6] = origin, direction: closest hits, on the GPU
+    std::vector<PyrHit> intersect(const std::vector<float>& rays, int device = 0, PyrCounters* counters = nullptr);
     FlatScene& flat() { return flat_; }
     size_t num_objects() { return flat_.num_triangles() + flat_.num_spheres() + flat_.num_planes(); } // world.rs:251-254
 

@@ -1050,6 +1050,14 @@ PyrScene* World::scene(int device) {
     return handle;
 }
 
+std::vector<PyrHit> World::intersect(const std::vector<float>& rays, int device, PyrCounters* counters) {
+    if (rays.size() % 6 != 0) throw ProjectError("intersect: rays must hold six floats each (origin, direction)");
+    std::vector<PyrHit> hits(rays.size() / 6);
+    float ms = 0.0f;
+    check_status(pyr_scene_intersect(scene(device), rays.data(), (uint32_t)hits.size(), hits.data(), &ms, counters));
+    return hits;
+}
+
 Camera Camera::from_project(const CameraProject& cam) { // cameras.rs:30-55
     Camera out;
     const float fov = eval_number(cam.fov);

@@ -4,6 +4,7 @@
 //   pyrite_host_tool dump   <scene> <data_dir> <out.bin>                      flatten only (no GPU): canonical scene bytes + camera + renderer
 //   pyrite_host_tool dump-project   <project.lua> <texel dir | -> <out.bin>    the same for a project file (lua_project.cpp)
 //   pyrite_host_tool render-project <project.lua> <texel dir | -> <seed> <out.png> [film.bin]   what `pyrite project.lua` does (main.rs:46-330)
+//   pyrite_host_tool intersect <scene> <data_dir> <rays.f32> <hits.bin>       World::intersect for a ray batch ([n][6] f32 -> PyrHit[n])
 //   pyrite_host_tool render <scene> <data_dir> <w> <h> <spp> <seed> <film.bin> [out.png]
 //                                                                             Renderer::render on device 0; film as raw {acc, weight} f32
 // scenes: c1 c2 spheres diamonds lamps textures      data_dir: pyrite_amd/data (cornell_spectra.json, cornell_box.obj, diamonds.obj)
@@ -258,6 +259,19 @@ int main(int argc, char** argv) {
             flat.add_world(project.world, argv[3]);
             std::printf("%s: ", argv[2]);
             write_dump(argv[4], flat, project);
+            return 0;
+        }
+        if (argc >= 6 && std::string(argv[1]) == "intersect") { // intersect <scene> <data_dir> <rays.f32> <hits.bin>
+            Project project = make_scene(argv[2], argv[3]);
+            std::unique_ptr<World> world = World::from_project(project.world, argv[3]);
+            std::ifstream in(argv[4], std::ios::binary);
+            std::vector<char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+            std::vector<float> rays(bytes.size() / 4);
+            std::memcpy(rays.data(), bytes.data(), rays.size() * 4);
+            const std::vector<PyrHit> hits = world->intersect(rays);
+            std::ofstream out(argv[5], std::ios::binary);
+            out.write(reinterpret_cast<const char*>(hits.data()), (std::streamsize)(hits.size() * sizeof(PyrHit)));
+            std::printf("%zu rays\n", hits.size());
             return 0;
         }
         if (argc >= 9 && std::string(argv[1]) == "render") {

@@ -259,6 +259,22 @@ def test_cpp_renders_a_project_file(host, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_world_intersect_matches_the_oracle(host, tmp_path):
+    """World::intersect through the C++ layer: closest hits of a ray batch equal the oracle's."""
+    import oracle
+    from test_gpu_parity import assert_same_hits, random_rays
+
+    rays = random_rays(20000, 3, [-5.5, 0.1, 0.1], [-0.1, 5.5, 5.4])
+    rays_path, hits_path = os.path.join(tmp_path, "rays.f32"), os.path.join(tmp_path, "hits.bin")
+    rays.astype("<f4").tofile(rays_path)
+    subprocess.check_call([HOST_TOOL, "intersect", "c2", DATA_DIR, rays_path, hits_path], stdout=subprocess.DEVNULL)
+    got = np.fromfile(hits_path, dtype=np.dtype([("distance", "<f4"), ("shape", "<u4"), ("u", "<f4"), ("v", "<f4")]))
+    world, _, _, _ = scenes.build(scenes.c2_cornell(8, 8, 1), seed=1)
+    want, _ = oracle.OracleScene(world).intersect(rays)
+    assert_same_hits(want, got)
+
+
+@pytest.mark.gpu
 def test_cpp_development_with_filter_and_white_balance(host, tmp_path):
     """image.filter / image.white (main.rs:190-238): the C++ layer evaluates the two programs at the sampling wavelengths and
     develops on the GPU; its PNG equals the Python front-end's development of the same film (cornell.lua's white = blackbody)."""
