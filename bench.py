@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric (Msamples/s of the camera-to-light renderer) on BASELINE.json's configs[1].
+"""bench.py -- BASELINE.json's metric (Msamples/s of the camera-to-light renderer) on the configuration the metric is quoted
+on: C3 = configs[2], the Cornell box with the 819,212-triangle mesh at 1920 x 1080 x 1024 spp (the largest single-GPU
+configuration; configs[3] is the same scene across 2/4/8 GPUs).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A *step* is one complete pass of the hot path over the workload: the whole C2 image (1024 x 1024, 256 spp = 268.4 M
-samples) rendered into a film that is already resident in HBM (scene uploaded and film allocated before the timed
-region). With N > 1 the image's tiles are split into N contiguous raster ranges (strong scaling: the image is fixed), every
-rank renders its range into its own film window and ONE RCCL gather brings the windows to rank 0; the gather is inside the
-step. Timing: barrier + synchronize on both sides of exactly K steps, max over ranks, rank 0 prints one JSON line.
+A *step* is one complete pass of the hot path over the workload: the whole image rendered into a film that is already
+resident in HBM (scene uploaded and film allocated before the timed region). With N > 1 the image's tiles are dealt
+round-robin to the ranks (strong scaling: the image is fixed), every rank renders its tiles in ONE launch into its own
+buffer of ringed tile blocks and ONE RCCL gather brings the buffers to rank 0, which adds them into the film; gather and
+assembly are inside the step (pyr_render_simple_sharded; see pyrite_amd/distributed.py). Timing: barrier + synchronize on
+both sides of exactly K steps, max over ranks, rank 0 prints one JSON line. `--workload C2|C1|C5` runs another BASELINE
+config instead.
 
 Extra objects on the line:
-  roofline      algorithmic bytes (32 B per box test, 36 B per triangle test, 16 B per sphere / plane
-                test, 52 B per shaded hit, 16 B per film exposure; counts from an instrumented run of the same launch,
-                outside the timed region) over the kernel's average launch duration measured with HIP events on the launch
-                stream, against the 8 TB/s HBM3E peak. `traffic` (PMC HBM bytes) comes from the rocprofv3 --pmc passes
-                whose summary is committed under profiles/ (null when no summary for this workload is present).
+  roofline      the dominant kernel of the workload. `achieved` = ALGORITHMIC bytes per launch (32 B
+                per box test, 36 B per triangle test, 16 B per sphere / plane test, 52 B per shaded hit, 16 B per film
+                exposure; counts from instrumented runs of the same launches -- same seeds -- outside the timed region) over
+                the kernel's average launch duration measured with HIP events on the launch stream, against the 8 TB/s
+                HBM3E peak. THIS `frac` is the number north_star's ">= 40 % of the HBM-read roofline" is compared with for
+                the render; `traversal_roofline.frac` is the same for World::intersect alone. `traffic` = PMC HBM bytes per
+                launch from the rocprofv3 --pmc passes committed under profiles/ (null when there is none for this
+                workload); `measured_hbm_GBps` = traffic / kernel time, what the fabric really moved. `bytes_per_sample` is
+                printed because the algorithmic figure rewards wasted tests: a better tree lowers both it and `achieved`.
+  c2            (N = 1, default workload only) configs[1], the 36-triangle Cornell box at 1024^2 x 256 spp, three steps: its
+                scene lives in LDS, so its algorithmic bytes are LDS reads and the object says "bound": "lds".
   cpu_baseline  the CPU oracle (oracle/liboracle.so, a port of the reference's algorithm -- the Rust reference cannot be
                 built here) timed on this host's cores, rank 0, N = 1 only, on a bounded sample of the same workload.
 """
@@ -29,10 +39,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (scene builder name, width, height, spp)
-    "C2": ("c2_cornell", 1024, 1024, 256),
-    "C1": ("c1_spheres", 256, 256, 64),
-    "C3": ("c3_mesh_in_box", 1920, 1080, 1024),
+    # name: (scene builder, builder keywords, width, height, spp)
+    "C3": ("c3_mesh_in_box", {}, 1920, 1080, 1024),
+    "C2": ("c2_cornell", {}, 1024, 1024, 256),
+    "C1": ("c1_spheres", {}, 256, 256, 64),
+    "C5": ("c3_mesh_in_box", {"glass": True, "bounces": 20}, 1920, 1080, 4096),
 }
 BYTES = dict(box_tests=32, triangle_tests=36, sphere_tests=16, plane_tests=16, shaded_hits=52, exposures=16)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
@@ -43,35 +54,46 @@ def algorithmic_bytes(counters):
 
 
 def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
-    """Time the oracle on the same scene and image with fewer samples per pixel (the loop is linear in spp, simple.rs:73)."""
+    """Time the oracle on the same scene and image with fewer samples per pixel (the loop is linear in spp, simple.rs:73).
+    Also reports how the port scales with threads (1 / 32 / all) on a few tiles, so the figure can be judged."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import copy
 
     import oracle
 
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t0 = time.perf_counter()
     sc = oracle.OracleScene(world)
+    build_s = time.perf_counter() - t0
     r = copy.copy(renderer)
-    # calibrate on a few central tiles, then size the sample for ~target_seconds
     r.pixel_samples = 1
     tiles = renderer.num_tiles(width, height)
-    probe = (tiles // 2, min(tiles, tiles // 2 + 4 * threads))
-    film = renderer.new_film(width, height)
-    t0 = time.perf_counter()
-    c = sc.render(r, cam, film, threads=threads, tile_range=probe)
-    rate = c["samples"] / max(time.perf_counter() - t0, 1e-6)
-    spp = int(max(1, min(renderer.pixel_samples, round(rate * target_seconds / (width * height)))))
+
+    def rate(n_threads, n_tiles):
+        a = max(0, tiles // 2 - n_tiles // 2)
+        film = renderer.new_film(width, height)
+        t = time.perf_counter()
+        c = sc.render(r, cam, film, threads=n_threads, tile_range=(a, min(tiles, a + n_tiles)))
+        return c["samples"] / max(time.perf_counter() - t, 1e-6)
+
+    scaling = {}
+    for n in sorted({1, min(32, threads), threads}):
+        scaling[str(n)] = round(rate(n, min(tiles, 4 * n)) / 1e6, 4)
+    spp = int(max(1, min(renderer.pixel_samples, round(scaling[str(threads)] * 1e6 * target_seconds / (width * height)))))
     r.pixel_samples = spp
     film = renderer.new_film(width, height)
     t0 = time.perf_counter()
     c = sc.render(r, cam, film, threads=threads)
     dt = time.perf_counter() - t0
+    sc.close()
     return {
         "value": round(c["samples"] / dt / 1e6, 4),
         "unit": "Msamples/s",
         "cores": threads,
         "kind": "port",
-        "sample": "same scene and %dx%d image at %d spp of %d (all tiles), %.1f s of CPU work" % (width, height, spp, renderer.pixel_samples, dt),
+        "sample": "same scene and %dx%d image at %d spp of %d (all tiles), %.1f s of CPU work (+ %.1f s BVH build, not counted)"
+                  % (width, height, spp, renderer.pixel_samples, dt, build_s),
+        "thread_scaling_Msamples_per_s": scaling,
     }
 
 
@@ -115,8 +137,171 @@ def load_traffic(workload):
             table = json.load(f)
         entry = table.get(workload)
         if entry:
-            return entry.get("hbm_bytes_per_launch")
-    return None
+            return entry.get("hbm_bytes_per_launch"), entry.get("kernel_ms")
+    return None, None
+
+
+class Workload:
+    """One BASELINE configuration on this rank's GPU: scene uploaded, film described, ready to be stepped."""
+
+    def __init__(self, name, args, torch, local_rank, world_size, rehearsal):
+        from pyrite_amd import abi, scenes
+
+        self.name, self.torch, self.abi = name, torch, abi
+        builder, kw, self.width, self.height, spp = WORKLOADS[name]
+        self.builder = builder
+        self.reduced = (args.spp is not None and args.spp != spp) or rehearsal
+        self.spp = args.spp or spp
+        project = getattr(scenes, builder)(width=self.width, height=self.height, pixel_samples=self.spp, **kw)
+        self.world, self.cam, self.renderer, _ = scenes.build(project, seed=args.seed)
+        for item in filter(None, args.dev.split(",")):
+            key, val = item.split("=")
+            setattr(self.renderer, key, int(val))
+            self.reduced = True
+        self.local_rank, self.world_size = local_rank, world_size
+        self.device = torch.device("cuda", local_rank)
+        self.world.scene(local_rank)  # BVH build + upload, outside the timed region
+        r = self.renderer
+        self.bins = r.spectrum_bins
+        self.film_desc = abi.PyrFilmDesc(self.width, self.height, self.bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
+        self.stream = torch.cuda.current_stream(self.device)
+        self.launch_events = []  # (start, stop) HIP events around every render launch of this rank, on the launch stream
+        self.native, self.collective = None, "torch.distributed.gather (RCCL)"
+        info = self.world.bvh_info(local_rank)
+        self.lds_resident = info["node_bytes"] + info["primitive_bytes"] <= 8 * 1024
+        # Sharding (pyrite_amd/distributed.py plan): a scene small enough to live in LDS costs about the same everywhere in
+        # the image (C2: slowest of 8 contiguous shares 1.03x the mean), so each rank gets one contiguous band of rows; a big
+        # scene does not (C3: 1.37x), so its tiles are dealt round-robin. One launch per rank either way. PYRITE_SHARDING overrides.
+        self.sharding = os.environ.get("PYRITE_SHARDING") or ("contiguous" if world_size == 1 or self.lds_resident else "tiles")
+
+    def render_share(self, share, buffer, flags=0):
+        """One launch: this rank's share into its buffer (pixel rows, or ringed tile blocks)."""
+        torch = self.torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(self.stream)
+        self.renderer.render_device(buffer.data_ptr(), self.film_desc, self.cam, self.world, stream=self.stream.cuda_stream, device=self.local_rank,
+                                    flags=flags, share=share)
+        b.record(self.stream)
+        self.launch_events.append((a, b))
+
+    def use_native(self, comm):
+        """Route the steps through pyr_render_simple_sharded (render + RCCL gather + assembly inside libpyrite_gpu.so)."""
+        self.native = comm
+        if comm.rank == 0:
+            self.native_film = self.torch.zeros((self.height, self.width, self.bins, 2), dtype=self.torch.float32, device=self.device)
+
+    def step(self):
+        from pyrite_amd import distributed as pdist
+
+        if getattr(self, "native", None) is not None:
+            torch = self.torch
+            film = getattr(self, "native_film", None)
+            if film is not None:
+                film.zero_()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+            self.native.render(self.renderer, self.cam, self.world, self.film_desc, film, stream=self.stream.cuda_stream)
+            b.record(self.stream)
+            self.launch_events.append((a, b))  # render + this rank's side of the gather (+ assembly on rank 0)
+            return film
+        return pdist.render_sharded(self.render_share, self.width, self.height, self.bins, self.renderer.tile_size, self.device,
+                                    sharding=self.sharding)
+
+    def counters_for_seeds(self, seeds_used):
+        """Instrumented launches of rank 0's share, one per distinct seed of the timed steps, averaged by use."""
+        from pyrite_amd import distributed as pdist
+
+        torch = self.torch
+        shares = pdist.plan(self.width, self.height, self.renderer.tile_size, self.world_size, self.sharding)
+        total, keep = None, self.renderer.seed
+        for seed in sorted(set(seeds_used)):
+            weight = seeds_used.count(seed)
+            self.renderer.seed = seed
+            window = torch.zeros((max(1, shares[0].pixels(self.width)), self.bins, 2), dtype=torch.float32, device=self.device)
+            self.render_share(shares[0], window, flags=self.abi.PYR_FLAG_COUNTERS)
+            torch.cuda.synchronize(self.device)
+            c = self.renderer.counters(self.world, self.local_rank)
+            total = {k: c[k] * weight for k in c} if total is None else {k: total[k] + c[k] * weight for k in c}
+            del window
+        self.renderer.seed = keep
+        n = len(seeds_used)
+        return {k: int(round(v / n)) for k, v in total.items()}
+
+    def kernel_name(self):
+        forced = os.environ.get("PYRITE_SCHEDULER")
+        staged = forced == "sm" or (forced != "sync" and not self.lds_resident)
+        return "render_kernel_sm (stage-scheduled)" if staged else "render_kernel (bounce-synchronous)"
+
+    def roofline(self, counters, kernel_ms, launches_per_step):
+        samples = self.width * self.height * self.spp
+        traversal = 32 * counters["box_tests"] + 36 * counters["triangle_tests"] + 16 * (counters["sphere_tests"] + counters["plane_tests"])
+        total = algorithmic_bytes(counters)
+        achieved = total / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_ms = load_traffic(self.name)
+        if self.reduced or self.world_size != 1:
+            traffic = traffic_ms = None  # the committed counters are for the full single-GPU launch
+        out = {
+            "bound": "lds" if self.lds_resident else "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "measured_hbm_GBps": round(traffic / ((traffic_ms or kernel_ms) * 1e-3) / 1e9, 1) if traffic else None,
+            "compared_with_target": "frac = algorithmic bytes / kernel time / 8 TB/s is what north_star's >= 0.40 is compared with",
+            "kernel": self.kernel_name(),
+            "kernel_ms": round(kernel_ms, 3),
+            "launches_per_step": launches_per_step,
+            "algorithmic_bytes_per_launch": int(total),
+            "bytes_per_sample": round(total / max(counters["samples"], 1), 1),
+            "traversal_bytes_per_launch": int(traversal),
+            "traversal_frac": round(traversal / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "counters": counters,
+        }
+        if self.lds_resident:
+            out["note"] = ("the scene (nodes + primitives) is staged in LDS: the algorithmic bytes are LDS reads and measure traversal work; "
+                           "HBM only sees the film's atomics (`traffic`)")
+        return out
+
+    def describe(self, world_size, total_weight):
+        r = self.renderer
+        samples = self.width * self.height * self.spp
+        expected_weight = float(samples) * r.spectrum_samples
+        return {
+            "workload": "%s: %s, %dx%d, %d spp%s" % (self.name, self.builder, self.width, self.height, self.spp,
+                                                    " (REDUCED: development run)" if self.reduced else ""),
+            "bounces": r.bounces, "light_samples": r.light_samples, "spectrum_samples": r.spectrum_samples,
+            "spectrum_bins": self.bins, "tile_size": r.tile_size, "triangles": len(self.world.flat.tri_material), "spheres": len(self.world.flat.spheres),
+            "parallelism": "one launch on one GPU" if world_size == 1 else "%s shares on %d GPUs (one launch per GPU), one film gather by %s"
+                           % (self.sharding, world_size, self.collective),
+            # samples that map outside the image are dropped as in the reference (film.rs:51-54): a few per 1e7
+            "film_weight": total_weight, "film_weight_expected": expected_weight,
+            "film_weight_check": "ok" if abs(total_weight - expected_weight) <= 1e-5 * expected_weight else "MISMATCH",
+        }
+
+
+def timed_steps(wl, steps, warmup, seed, fence, dist, world_size):
+    """W untimed steps, then exactly K steps between two fences; returns (ms_per_step max over ranks, film on rank 0, seeds)."""
+    torch = wl.torch
+    for _ in range(warmup):
+        wl.step()
+    fence()
+    wl.launch_events.clear()
+    seeds_used = []
+    t0 = time.perf_counter()
+    film = None
+    for k in range(steps):
+        wl.renderer.seed = seed + k % 3  # SURVEY 8(d): seeds 1, 2, 3 in turn; a step is one full render either way
+        seeds_used.append(wl.renderer.seed)
+        film = wl.step()
+    wl.renderer.seed = seed
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wl.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed * 1e3 / max(steps, 1), film, seeds_used
 
 
 def main():
@@ -124,19 +309,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (development only: the line is then marked reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traversal", action="store_true", help="skip the BVH-traversal roofline measurement on the C3 scene")
+    ap.add_argument("--no-c2", action="store_true", help="skip the extra C2 (configs[1]) measurement")
     ap.add_argument("--dev", default="", help="development overrides, e.g. spectrum_samples=1,light_samples=0,bounces=2 (marks the line reduced)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-
-    from pyrite_amd import abi, scenes
-    from pyrite_amd import distributed as pdist
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -160,8 +343,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-
-    if world_size > 1:
         # bring up the communicator and the point-to-point channels the gather uses before anything is timed (RCCL creates
         # them lazily at the first collective of each kind): one tiny gather, the same call the step makes
         probe = torch.zeros(16, dtype=torch.float32, device="cpu" if rehearsal else device)
@@ -169,72 +350,41 @@ def main():
         if not rehearsal:
             torch.cuda.synchronize(device)
 
-    builder, width, height, spp = WORKLOADS[args.workload]
-    reduced = (args.spp is not None and args.spp != spp) or rehearsal
-    spp = args.spp or spp
-    project = getattr(scenes, builder)(width=width, height=height, pixel_samples=spp)
-    world, cam, renderer, _ = scenes.build(project, seed=args.seed)
-    for item in filter(None, args.dev.split(",")):
-        key, val = item.split("=")
-        setattr(renderer, key, int(val))
-        reduced = True
-    world.scene(local_rank)  # BVH build + upload, outside the timed region
-    bins = renderer.spectrum_bins
-    film_desc = abi.PyrFilmDesc(width, height, bins, renderer.spectrum_span[0], renderer.spectrum_span[1] - renderer.spectrum_span[0])
-    stream = torch.cuda.current_stream(device)
-
-    launch_events = []  # (start, stop) HIP events around every render launch of this rank, on the launch stream
-
-    def render_window(tile_range, rows, window, flags=0):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(stream)
-        renderer.render_device(window.data_ptr(), film_desc, cam, world, stream=stream.cuda_stream, device=local_rank, flags=flags,
-                               tile_range=tile_range, film_rows=rows)
-        b.record(stream)
-        launch_events.append((a, b))
-
-    # Sharding (pyrite_amd/distributed.py plan): a scene small enough to live in LDS costs about the same everywhere in the
-    # image (C2: slowest of 8 contiguous shares 1.03x the mean), so each rank gets one contiguous band = one launch; a big
-    # scene does not (C3: 1.37x), so its tile rows are dealt round-robin. PYRITE_SHARDING overrides.
-    info0 = world.bvh_info(local_rank)
-    sharding = os.environ.get("PYRITE_SHARDING") or ("contiguous" if world_size == 1 or info0["node_bytes"] + info0["primitive_bytes"] <= 8 * 1024 else "cyclic")
-
-    def step():
-        return pdist.render_sharded(render_window, width, height, bins, renderer.tile_size, device, sharding=sharding)
-
     def fence():
         if world_size > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    launch_events.clear()
-    start_evt, stop_evt = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    start_evt.record(stream)
-    film = None
-    for k in range(args.steps):
-        renderer.seed = args.seed + k % 3  # seeds 1, 2, 3 in turn; a step is one full render either way
-        film = step()
-    renderer.seed = args.seed
-    stop_evt.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
-    samples = width * height * spp
+    wl = Workload(args.workload, args, torch, local_rank, world_size, rehearsal)
+    if world_size > 1 and not rehearsal and wl.sharding == "tiles" and os.environ.get("PYRITE_BENCH_COLLECTIVE", "native") == "native":
+        # The gather inside the library (pyr_render_simple_sharded: grouped ncclSend / ncclRecv). If the communicator cannot be
+        # made on this node, every rank falls back TOGETHER to torch.distributed.gather over the same plan, and the line says so.
+        from pyrite_amd import distributed as pdist
+
+        ok, comm, why = 1, None, ""
+        try:
+            comm = pdist.NativeSharded(local_rank)
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the other collective", reported below
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            wl.use_native(comm)
+            wl.collective = "pyr_render_simple_sharded (ncclSend/ncclRecv group inside libpyrite_gpu.so)"
+        else:
+            if comm is not None:
+                comm.close()
+            wl.collective = "torch.distributed.gather (RCCL); the native communicator failed on some rank%s" % (": " + why if why else "")
+    ms_per_step, film, seeds_used = timed_steps(wl, args.steps, args.warmup, args.seed, fence, dist, world_size)
+    samples = wl.width * wl.height * wl.spp
     value = samples / (ms_per_step * 1e-3) / 1e6
 
-    line = None
+    line, mismatch = None, False
     if rank == 0:
         # sanity: every sample exposed spectrum_samples wavelengths into the gathered film
         total_weight = float(film[..., 1].sum(dtype=torch.float64).item()) if film is not None else 0.0
-        expected_weight = float(samples) * renderer.spectrum_samples
+        config = wl.describe(world_size, total_weight)
+        mismatch = config["film_weight_check"] != "ok"
         line = {
             "metric": "Msamples/sec",
             "value": round(value, 3),
@@ -248,65 +398,41 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "seeds": sorted({args.seed + k % 3 for k in range(args.steps)}),
-            "config": {
-                "workload": "%s: %s, %dx%d, %d spp%s" % (args.workload, builder, width, height, spp, " (REDUCED spp: development run)" if reduced else ""),
-                "bounces": renderer.bounces, "light_samples": renderer.light_samples, "spectrum_samples": renderer.spectrum_samples,
-                "spectrum_bins": bins, "tile_size": renderer.tile_size, "triangles": len(world.flat.tri_material), "spheres": len(world.flat.spheres),
-                "parallelism": "one launch on one GPU" if world_size == 1 else "%s tile bands on %d GPUs, one film gather" % (sharding, world_size),
-                # samples that map outside the image are dropped as in the reference (film.rs:51-54): a few per 1e7
-                "film_weight": total_weight, "film_weight_expected": expected_weight,
-                "film_weight_check": "ok" if abs(total_weight - expected_weight) <= 1e-5 * expected_weight else "MISMATCH",
-            },
+            "seeds": sorted(set(seeds_used)),
+            "config": config,
         }
     del film
 
     if rank == 0:
-        # kernel duration from HIP events on the launch stream: one launch per step at N = 1, one per band of this rank's
-        # share otherwise (the figure is then rank 0's kernel time and rank 0's algorithmic bytes, i.e. per GPU)
-        kernel_ms = sum(a.elapsed_time(b) for a, b in launch_events) / max(args.steps, 1)
-        # algorithmic bytes per step: instrumented run of the same launches, outside the timed region
-        shares = pdist.plan(width, height, renderer.tile_size, world_size, sharding)
-        counters = None
-        for tile_range, (first_row, rows) in shares[0]:
-            window = torch.zeros((rows, width, bins, 2), dtype=torch.float32, device=device)
-            render_window(tile_range, (first_row, rows), window, flags=abi.PYR_FLAG_COUNTERS)
-            torch.cuda.synchronize(device)
-            c = renderer.counters(world, local_rank)
-            counters = c if counters is None else {k: counters[k] + c[k] for k in c}
-            del window
-        info = world.bvh_info(local_rank)
-        lds_resident = info["node_bytes"] + info["primitive_bytes"] <= 8 * 1024
-        forced = os.environ.get("PYRITE_SCHEDULER")
-        staged = forced == "sm" or (forced != "sync" and not lds_resident)
-        kernel_name = "render_kernel_sm (stage-scheduled)" if staged else "render_kernel (bounce-synchronous)"
-        traversal = 32 * counters["box_tests"] + 36 * counters["triangle_tests"] + 16 * (counters["sphere_tests"] + counters["plane_tests"])
-        total = algorithmic_bytes(counters)
-        achieved = total / (kernel_ms * 1e-3) / 1e9
-        line["roofline"] = {
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": load_traffic(args.workload),
-            "kernel": kernel_name,
-            "kernel_ms": round(kernel_ms, 3),
-            "launches_per_step": len(shares[0]),
-            "algorithmic_bytes_per_launch": int(total),
-            "traversal_bytes_per_launch": int(traversal),
-            "traversal_frac": round(traversal / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "counters": counters,
-        }
+        # kernel duration from HIP events on the launch stream: one launch per step and rank (the figure is rank 0's kernel
+        # time and rank 0's algorithmic bytes, i.e. per GPU)
+        launches = len(wl.launch_events)
+        kernel_ms = sum(a.elapsed_time(b) for a, b in wl.launch_events) / max(args.steps, 1)
+        counters = wl.counters_for_seeds(seeds_used)
+        line["roofline"] = wl.roofline(counters, kernel_ms, launches // max(args.steps, 1))
         if world_size == 1 and not args.no_traversal:
             line["traversal_roofline"] = traversal_roofline(local_rank)
+        if world_size == 1 and args.workload == "C3" and not args.no_c2 and not wl.reduced:
+            # configs[1] beside the headline: three steps of the LDS-resident Cornell box
+            c2_args = argparse.Namespace(**{**vars(args), "spp": None, "dev": ""})
+            c2 = Workload("C2", c2_args, torch, local_rank, 1, False)
+            c2_ms, c2_film, c2_seeds = timed_steps(c2, 3, 1, args.seed, fence, dist, 1)
+            c2_kernel_ms = sum(a.elapsed_time(b) for a, b in c2.launch_events) / 3
+            c2_config = c2.describe(1, float(c2_film[..., 1].sum(dtype=torch.float64).item()))
+            mismatch = mismatch or c2_config["film_weight_check"] != "ok"
+            del c2_film
+            line["c2"] = {"value": round(c2.width * c2.height * c2.spp / (c2_ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "steps": 3, "warmup": 1,
+                          "ms_per_step": round(c2_ms, 3), "config": c2_config,
+                          "roofline": c2.roofline(c2.counters_for_seeds(c2_seeds), c2_kernel_ms, 1)}
+            c2.world.close()
         if world_size == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(world, cam, renderer, width, height)
-    if rank == 0:
+            line["cpu_baseline"] = cpu_baseline(wl.world, wl.cam, wl.renderer, wl.width, wl.height)
         print(json.dumps(line), flush=True)
     if world_size > 1:
         dist.barrier()  # rank 0 ran the instrumented pass above: leave together
         dist.destroy_process_group()
+    if mismatch:
+        sys.exit("film weight check failed: the film does not hold samples x spectrum_samples exposures")
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PYR_ABI_VERSION 2
+#define PYR_ABI_VERSION 3
 
 typedef enum PyrStatus {
     PYR_OK = 0,
@@ -73,11 +73,24 @@ typedef struct PyrFilmDesc {
  *
  * Sharding: a call renders the raster-order tile range [tile_begin, tile_end) (tile index
  * ty*tiles_x + tx over the grid of make_tiles, renderer/algorithm.rs:152-188); tile_end == 0 means
- * "all tiles". The film buffer handed to the call covers pixel rows
- * [film_row_begin, film_row_begin + film_row_count) of the image (film_row_count == 0 means the whole
- * image); exposures that map outside that window are dropped exactly like exposures outside the
- * image (film.rs:51-54,92). Multi-GPU hosts give each rank a tile range and a row window (plus a
- * one-row halo) and gather the windows. */
+ * "all tiles"; with tile_stride > 1 only the tiles tile_begin, tile_begin + tile_stride, ... below tile_end are
+ * rendered (the multi-GPU plan deals tiles round-robin: rank r of n renders tile_begin = r, tile_stride = n).
+ * Tiles are independent units in the reference too: each has its own RNG and writes its own pixels
+ * (renderer/simple.rs:36-55).
+ *
+ * film_layout says what the film buffer handed to the call holds:
+ *   PYR_FILM_ROWS         pixel rows [film_row_begin, film_row_begin + film_row_count) of the image in the film.rs:56 layout
+ *                         (film_row_count == 0 means the whole image);
+ *   PYR_FILM_TILE_BLOCKS  one block per rendered tile, in the order the tiles are rendered: block k belongs to tile
+ *                         tile_begin + k*stride and holds (tile_size + 2)^2 pixels x bins grains -- the tile's
+ *                         tile_size x tile_size pixel square with a one-pixel ring around it; image pixel (x, y) sits
+ *                         at block-local (x - tile_x0 + 1, y - tile_y0 + 1), row-major, bins grains per pixel. The ring is
+ *                         there because Film::expose recomputes the pixel from the view-plane position (film.rs:233-246) and
+ *                         rounding can move a sample drawn on a tile edge into the neighbouring pixel (~1e-6 per sample).
+ *                         pyr_film_blocks_assemble[_device] adds such blocks into a whole-image film.
+ * Exposures that map outside the buffer are dropped exactly like exposures outside the image (film.rs:51-54,92). */
+#define PYR_FILM_ROWS 0u
+#define PYR_FILM_TILE_BLOCKS 1u
 typedef struct PyrRenderParams {
     uint32_t bounces;
     uint32_t pixel_samples;
@@ -90,6 +103,8 @@ typedef struct PyrRenderParams {
     uint32_t tile_end;
     uint32_t film_row_begin;
     uint32_t film_row_count;
+    uint32_t tile_stride; /* 0 and 1 both mean every tile of the range */
+    uint32_t film_layout; /* PYR_FILM_ROWS | PYR_FILM_TILE_BLOCKS */
 } PyrRenderParams;
 
 /* == Camera::Perspective {transform, view_plane, focus_distance, aperture}: cameras.rs:20-27.
@@ -372,6 +387,51 @@ typedef struct PyrBvhInfo {
     uint64_t primitive_bytes;
 } PyrBvhInfo;
 int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out);
+
+/* ---------------------------------------------------------------- multi-GPU -----------
+ * The reference is one process with shared memory; its unit of parallel work is the tile (renderer/simple.rs:36-55: every
+ * tile has its own RNG and exposes its own pixels, renderer/mod.rs:125-189 hands tiles to worker threads). Here the scene
+ * is replicated on every GPU, the tiles of the image are dealt round-robin to the ranks (rank r of n renders tiles
+ * r, r + n, ...: every rank sees every part of the image, which balances the cost without measuring it), every rank
+ * renders its tiles in ONE launch into a private PYR_FILM_TILE_BLOCKS buffer with no data-path collective, and ONE gather
+ * -- a group of ncclSend / ncclRecv over xGMI (RCCL) -- brings the blocks to rank 0, which adds them into the film.
+ * With the per-(tile, iteration) RNG the n-GPU film equals the 1-GPU film up to the order of the float additions. */
+
+/* Grains a PYR_FILM_TILE_BLOCKS buffer needs for the tiles `params` selects (tile_begin / tile_end / tile_stride /
+ * tile_size); 0 when the arguments are invalid. */
+uint64_t pyr_film_blocks_grains(const PyrFilmDesc* film, const PyrRenderParams* params);
+
+/* Adds the blocks a render with these `params` (film_layout = PYR_FILM_TILE_BLOCKS) produced into `film_device`, a
+ * whole-image film in the film.rs:56 layout; both buffers on `device`, enqueued on `hip_stream`. Ring pixels outside the
+ * image do not exist and are skipped (nothing was exposed there). */
+int pyr_film_blocks_assemble_device(const PyrFilmDesc* film, const PyrRenderParams* params, const PyrGrain* blocks_device,
+                                    PyrGrain* film_device, int device, void* hip_stream);
+
+/* One process per GPU (torch.distributed, MPI, ...): a communicator over RCCL. Rank 0 obtains an id with
+ * pyr_comm_unique_id (ncclGetUniqueId; 128 bytes), the host brings it to the other ranks by whatever means it has, and
+ * every rank calls pyr_comm_create (ncclCommInitRank) with its device. librccl is loaded when the first of these is
+ * called; single-GPU use of the library never touches it. */
+#define PYR_COMM_ID_BYTES 128
+typedef struct PyrComm PyrComm;
+int pyr_comm_unique_id(uint8_t id_out[PYR_COMM_ID_BYTES]);
+int pyr_comm_create(const uint8_t id[PYR_COMM_ID_BYTES], int rank, int num_ranks, int device, PyrComm** out_comm);
+void pyr_comm_destroy(PyrComm* comm);
+
+/* This rank's part of a sharded render, enqueued on `hip_stream` without synchronising: of the tiles `params` selects
+ * (normally all: tile_begin = tile_end = 0, tile_stride <= 1) rank r renders every num_ranks-th starting at the r-th,
+ * sends its blocks to rank 0 (grouped ncclSend / ncclRecv: the one gather), and rank 0 adds everybody's blocks into
+ * `film_device_rank0` (a whole-image film on rank 0's device; ignored on the other ranks, may be NULL there).
+ * `scene` must live on the communicator's device. Working buffers are kept on the communicator between calls. */
+int pyr_render_simple_sharded(PyrComm* comm, PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film,
+                              const PyrRenderParams* params, PyrGrain* film_device_rank0, void* hip_stream);
+
+/* One process driving several GPUs (what a Rust host does with its thread pool): `scenes[i]` is the scene created on
+ * the i-th device to use. Blocking; one host thread per device; the same plan and the same gather as above
+ * (ncclCommInitAll). Adds the exposures into `film_inout`, a HOST film of the whole image. If the same device appears
+ * more than once (a test rig: several logical ranks on one GPU, which RCCL refuses) the blocks travel by
+ * hipMemcpyPeerAsync instead. `on_status` (may be NULL) is called on the calling thread only. */
+int pyr_render_simple_multi(PyrScene* const* scenes, uint32_t num_devices, const PyrCamera* camera, const PyrFilmDesc* film,
+                            const PyrRenderParams* params, PyrGrain* film_inout, PyrProgressFn on_status, void* user);
 
 /* ---------------------------------------------------------------- film development ("next" row f1) -------------
  * The step after the hot path: main.rs:315-327 turns every developed pixel spectrum into an 8-bit sRGB pixel through

@@ -1396,7 +1396,9 @@ struct Bounce { // tracer.rs:157-167
     V3 incident, position, normal;
     float texture[2];
     float probability;
-    std::vector<DirectLight> direct_light;
+    // Vec<DirectLight> in the reference (tracer.rs:166). The light samples of all bounces of a path sit in one array the
+    // tile's loop reuses from sample to sample (no allocation per bounce); a bounce names its slice.
+    uint32_t light_first = 0, light_count = 0;
 };
 
 // trace_direct, tracer.rs:347-442. The reference panics in pick_lamp's gen_range(0..0) when the world has no
@@ -1473,8 +1475,8 @@ inline bool trace_directional(const OracleScene& s, V3 ray, uint32_t& color) {
 }
 
 // trace, tracer.rs:208-345.
-void trace(const OracleScene& s, std::vector<Bounce>& path, Rng& rng, Ray ray, float wavelength, uint32_t bounces, uint32_t light_samples,
-           Exe& exe, Counters& c) {
+void trace(const OracleScene& s, std::vector<Bounce>& path, std::vector<DirectLight>& lights, Rng& rng, Ray ray, float wavelength, uint32_t bounces,
+           uint32_t light_samples, Exe& exe, Counters& c) {
     bool sample_light = true;
     uint32_t light_sample_events = 0;
     for (uint32_t b = 0; b < bounces; ++b) {
@@ -1504,7 +1506,9 @@ void trace(const OracleScene& s, std::vector<Bounce>& path, Rng& rng, Ray ray, f
                     sample_light = !sc.has_brdf || light_samples == 0;
                     if (sc.has_brdf) {
                         light_sample_events += 1;
-                        trace_direct(s, rng, light_samples, wavelength, ray.direction, position, normal, exe, bounce.direct_light, c);
+                        bounce.light_first = (uint32_t)lights.size();
+                        trace_direct(s, rng, light_samples, wavelength, ray.direction, position, normal, exe, lights, c);
+                        bounce.light_count = (uint32_t)lights.size() - bounce.light_first;
                     }
                 } else {
                     sample_light = true;
@@ -1565,7 +1569,7 @@ struct SpectralSample { // (Sample {brightness, wavelength, weight}, reflectance
     float brightness, wavelength, weight, reflectance;
 };
 
-void contribute(const Bounce& bounce, SpectralSample& main_sample, SpectralSample* additional, size_t n_additional, Exe& exe) {
+void contribute(const Bounce& bounce, const DirectLight* lights, SpectralSample& main_sample, SpectralSample* additional, size_t n_additional, Exe& exe) {
     if (bounce.ty == BOUNCE_EMISSION) {
         ProgramInput initial{main_sample.wavelength, bounce.normal, bounce.incident, {bounce.texture[0], bounce.texture[1]}};
         Memoized m(exe, bounce.color, initial);
@@ -1584,7 +1588,8 @@ void contribute(const Bounce& bounce, SpectralSample& main_sample, SpectralSampl
                 additional[i].reflectance *= m.run() * bounce.probability;
             }
         }
-        for (const DirectLight& direct : bounce.direct_light) {
+        for (uint32_t li = 0; li < bounce.light_count; ++li) {
+            const DirectLight& direct = lights[bounce.light_first + li];
             ProgramInput initial{main_sample.wavelength, direct.normal, direct.incident, {direct.texture[0], direct.texture[1]}};
             Memoized m(exe, direct.color, initial);
             main_sample.brightness += m.run() * direct.probability * main_sample.reflectance;
@@ -1692,17 +1697,29 @@ struct FilmView {
     PyrGrain* grains;
     PyrFilmDesc desc;
     uint32_t row_begin, row_count;
+    // PYR_FILM_TILE_BLOCKS (pyrite_gpu.h): one (tile_size + 2)^2 block per rendered tile, the tile's pixels with a ring of one
+    // pixel; block k belongs to tile tile_begin + k * tile_stride. Not a reference concept: the multi-GPU plan's buffer.
+    uint32_t layout = PYR_FILM_ROWS, tile_size = 0, tiles_x = 0, tile_begin = 0, tile_stride = 1;
 };
 
 // Film::expose (film.rs:89-95) + Grain::increment (film.rs:145-162). The reference gives up after five failed
 // compare-exchange attempts and drops the sample; the oracle retries until it succeeds (deterministic totals).
-inline void film_expose(const FilmView& film, float px, float py, float wavelength, float brightness, float weight, Counters& c) {
+inline void film_expose(const FilmView& film, uint32_t tile, float px, float py, float wavelength, float brightness, float weight, Counters& c) {
     uint32_t grain = wavelength_to_grain(wavelength, film.desc.wl_start, film.desc.wl_width, film.desc.bins);
     uint64_t x, y;
     if (!to_pixel(film.desc.width, film.desc.height, px, py, x, y)) return;
     if (x >= film.desc.width || y >= film.desc.height) return; // Film::get_pixel, film.rs:51-54
-    if (y < film.row_begin || y >= (uint64_t)film.row_begin + film.row_count) return;
-    size_t index = ((size_t)x + (size_t)(y - film.row_begin) * film.desc.width) * film.desc.bins + grain;
+    size_t index;
+    if (film.layout == PYR_FILM_TILE_BLOCKS) {
+        const uint64_t side = (uint64_t)film.tile_size + 2, tx = tile % film.tiles_x, ty = tile / film.tiles_x;
+        const int64_t bx = (int64_t)x + 1 - (int64_t)(tx * film.tile_size), by = (int64_t)y + 1 - (int64_t)(ty * film.tile_size);
+        if (bx < 0 || by < 0 || bx >= (int64_t)side || by >= (int64_t)side) return;
+        const uint64_t block = (tile - film.tile_begin) / film.tile_stride;
+        index = (size_t)(((block * side + (uint64_t)by) * side + (uint64_t)bx) * film.desc.bins + grain);
+    } else {
+        if (y < film.row_begin || y >= (uint64_t)film.row_begin + film.row_count) return;
+        index = ((size_t)x + (size_t)(y - film.row_begin) * film.desc.width) * film.desc.bins + grain;
+    }
     static_assert(sizeof(PyrGrain) == 8, "grain must be 8 bytes");
     auto* cell = reinterpret_cast<std::atomic<uint64_t>*>(&film.grains[index]);
     uint64_t current = cell->load(std::memory_order_relaxed);
@@ -1751,13 +1768,17 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
     additional_samples.reserve(p.spectrum_samples);
     std::vector<Bounce> path;
     path.reserve(p.bounces);
+    std::vector<DirectLight> lights;
+    lights.reserve(2 * (size_t)p.light_samples);
     Exe exe(&s);
 
+    static const char* const dbg = std::getenv("ORACLE_DEBUG_PIXEL"); // read once, not per sample
     uint64_t iterations = (uint64_t)tile.width * tile.height * (uint64_t)p.pixel_samples;
     for (uint64_t i = 0; i < iterations; ++i) {
         Rng rng = rng_seed(p.seed, tile.raster_index, i);
         additional_samples.clear();
         path.clear();
+        lights.clear();
         c.samples++;
 
         // Tile::sample_point, algorithm.rs:113-119
@@ -1785,15 +1806,15 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
         additional_samples.pop_back();
         float wavelength = main_sample.wavelength;
 
-        trace(s, path, rng, ray, wavelength, p.bounces, p.light_samples, exe, c);
+        trace(s, path, lights, rng, ray, wavelength, p.bounces, p.light_samples, exe, c);
 
         bool use_additional = true;
         for (const Bounce& bounce : path) {
             use_additional = !bounce.dispersed && use_additional;
-            contribute(bounce, main_sample, additional_samples.data(), use_additional ? additional_samples.size() : 0, exe);
+            contribute(bounce, lights.data(), main_sample, additional_samples.data(), use_additional ? additional_samples.size() : 0, exe);
         }
 
-        if (const char* dbg = std::getenv("ORACLE_DEBUG_PIXEL")) { // developer aid: ORACLE_DEBUG_PIXEL=x,y prints the samples of one pixel
+        if (dbg) { // developer aid: ORACLE_DEBUG_PIXEL=x,y prints the samples of one pixel
             unsigned dx = 0, dy = 0;
             uint64_t qx, qy;
             if (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy) {
@@ -1802,15 +1823,18 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
                 for (const Bounce& b : path) {
                     std::fprintf(stderr, "    bounce type %d color %u prob %.9g dispersed %d pos (%.9g %.9g %.9g) normal (%.6f %.6f %.6f) out (%.6f %.6f %.6f) lights %zu:", (int)b.ty,
                                  b.color, b.probability, (int)b.dispersed, b.position.x, b.position.y, b.position.z, b.normal.x, b.normal.y, b.normal.z, b.out.x, b.out.y,
-                                 b.out.z, b.direct_light.size());
-                    for (const DirectLight& dl : b.direct_light) std::fprintf(stderr, " [color %u prob %.9g dir (%.9g %.9g %.9g)]", dl.color, dl.probability, dl.incident.x, dl.incident.y, dl.incident.z);
+                                 b.out.z, (size_t)b.light_count);
+                    for (uint32_t li = 0; li < b.light_count; ++li) {
+                        const DirectLight& dl = lights[b.light_first + li];
+                        std::fprintf(stderr, " [color %u prob %.9g dir (%.9g %.9g %.9g)]", dl.color, dl.probability, dl.incident.x, dl.incident.y, dl.incident.z);
+                    }
                     std::fprintf(stderr, "\n");
                 }
             }
         }
-        film_expose(film, px, py, main_sample.wavelength, main_sample.brightness, main_sample.weight, c);
+        film_expose(film, tile.raster_index, px, py, main_sample.wavelength, main_sample.brightness, main_sample.weight, c);
         if (use_additional)
-            for (const SpectralSample& sm : additional_samples) film_expose(film, px, py, sm.wavelength, sm.brightness, sm.weight, c);
+            for (const SpectralSample& sm : additional_samples) film_expose(film, tile.raster_index, px, py, sm.wavelength, sm.brightness, sm.weight, c);
     }
 }
 
@@ -1969,11 +1993,21 @@ int oracle_render_simple(OracleScene* scene, const PyrCamera* camera, const PyrF
         return fail(PYR_ERR_INVALID_ARGUMENT, "zero-sized parameter");
     std::vector<Tile> tiles = make_tiles(film->width, film->height, params->tile_size);
     uint32_t tile_begin = params->tile_begin, tile_end = params->tile_end ? params->tile_end : (uint32_t)tiles.size();
+    const uint32_t tile_stride = std::max(1u, params->tile_stride);
     std::vector<Tile> selected;
     for (const Tile& t : tiles)
-        if (t.raster_index >= tile_begin && t.raster_index < tile_end) selected.push_back(t);
+        if (t.raster_index >= tile_begin && t.raster_index < tile_end && (t.raster_index - tile_begin) % tile_stride == 0) selected.push_back(t);
     FilmView view{film_inout, *film, params->film_row_begin, params->film_row_count ? params->film_row_count : film->height};
     if ((uint64_t)view.row_begin + view.row_count > film->height) return fail(PYR_ERR_INVALID_ARGUMENT, "film window exceeds the image");
+    if (params->film_layout > PYR_FILM_TILE_BLOCKS) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown film layout");
+    if (params->film_layout == PYR_FILM_TILE_BLOCKS) {
+        if (params->film_row_begin || params->film_row_count) return fail(PYR_ERR_INVALID_ARGUMENT, "a film of tile blocks has no row window");
+        view.layout = PYR_FILM_TILE_BLOCKS;
+        view.tile_size = params->tile_size;
+        view.tiles_x = (film->width + params->tile_size - 1) / params->tile_size;
+        view.tile_begin = tile_begin;
+        view.tile_stride = tile_stride;
+    }
 
     int n_threads = std::max(1, threads);
     std::atomic<size_t> next{0};

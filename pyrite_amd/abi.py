@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes and that every declared symbol is exported."""
 import ctypes as C
 
-PYR_ABI_VERSION = 2
+PYR_ABI_VERSION = 3
 
 PYR_OK = 0
 PYR_ERR_INVALID_ARGUMENT = -1
@@ -11,6 +11,8 @@ PYR_ERR_DEVICE = -3
 PYR_ERR_OUT_OF_MEMORY = -4
 
 PYR_FLAG_COUNTERS = 1
+PYR_FILM_ROWS, PYR_FILM_TILE_BLOCKS = 0, 1
+PYR_COMM_ID_BYTES = 128
 
 # PyrOp
 OP_NUMBER, OP_VECTOR, OP_RGB, OP_SPECTRUM, OP_COLOR_TEXTURE, OP_MONO_TEXTURE, OP_RGB_SPECTRUM = range(7)
@@ -53,6 +55,8 @@ class PyrRenderParams(C.Structure):
         ("tile_end", C.c_uint32),
         ("film_row_begin", C.c_uint32),
         ("film_row_count", C.c_uint32),
+        ("tile_stride", C.c_uint32),
+        ("film_layout", C.c_uint32),
     ]
 
 
@@ -253,6 +257,19 @@ ENTRY_POINTS = {
     "pyr_scene_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(PyrCounters)]),
     "pyr_scene_intersect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pyr_scene_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(PyrBvhInfo)]),
+    "pyr_film_blocks_grains": (C.c_uint64, [C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams)]),
+    "pyr_film_blocks_assemble_device": (C.c_int, [C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pyr_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pyr_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pyr_comm_destroy": (None, [C.c_void_p]),
+    "pyr_render_simple_sharded": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(PyrCamera), C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams), C.c_void_p, C.c_void_p],
+    ),
+    "pyr_render_simple_multi": (
+        C.c_int,
+        [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(PyrCamera), C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams), C.c_void_p, PyrProgressFn, C.c_void_p],
+    ),
     "pyr_film_develop": (C.c_int, [C.POINTER(PyrFilmDesc), C.c_void_p, C.POINTER(PyrDevelopParams), C.c_void_p, C.c_int]),
     "pyr_film_develop_device": (C.c_int, [C.POINTER(PyrFilmDesc), C.c_void_p, C.POINTER(PyrDevelopParams), C.c_void_p, C.c_int, C.c_void_p]),
 }

@@ -9,8 +9,8 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 OUT = os.path.join(CSRC, "libpyrite_gpu.so")
-SOURCES = ["kernels.hip", "api.cpp", "bvh.cpp"]
-HEADERS = ["bvh.h", "device_scene.h", os.path.join("..", "..", "include", "pyrite_gpu.h")]
+SOURCES = ["kernels.hip", "api.cpp", "multi.cpp", "bvh.cpp"]
+HEADERS = ["bvh.h", "device_scene.h", "api_internal.h", os.path.join("..", "..", "include", "pyrite_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
@@ -81,7 +81,7 @@ def build_host(force=False, verbose=False):
 def build(force=False, extra_flags=(), verbose=False):
     build_images(force, verbose)
     if force or stale():
-        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
@@ -89,6 +89,23 @@ def build(force=False, extra_flags=(), verbose=False):
     return OUT
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """A/B builds of the kernels (developer tool): csrc/variants/lib_<name>.so with extra -D flags, loaded through
+    PYRITE_GPU_LIB. Never a CPU path: the same sources, other compile-time switches."""
+    out_dir = os.path.join(CSRC, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "lib_%s.so" % name)
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out] + SOURCES + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m pyrite_amd.build --variant NAME -DFLAG ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+        sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)
     print(OUT)

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "api_internal.h"
 #include "bvh.h"
 #include "device_scene.h"
 
@@ -60,7 +61,11 @@ int validate(const PyrSceneDesc* d) {
     if ((d->num_triangles && (!d->tri_positions || !d->tri_normals || !d->tri_material)) || (d->num_spheres && (!d->spheres || !d->sphere_material)) ||
         (d->num_planes && (!d->planes || !d->plane_material)))
         return fail(PYR_ERR_INVALID_ARGUMENT, "null geometry array");
-    if (d->num_triangles >= (1u << 28) || d->num_spheres >= (1u << 28)) return fail(PYR_ERR_INVALID_ARGUMENT, "too many primitives");
+    // a leaf code packs (first_primitive << 3 | count) into 31 bits (bvh.h): the primitives together must stay below 2^28
+    if ((uint64_t)d->num_triangles + d->num_spheres >= (1ull << 28)) return fail(PYR_ERR_INVALID_ARGUMENT, "too many primitives");
+    if ((d->num_programs && !d->programs) || (d->num_instrs && !d->instrs) || (d->num_materials && !d->materials) || (d->num_components && !d->components) ||
+        (d->num_lamps && !d->lamps) || (d->num_spectra && !d->spectra) || (d->num_spectrum_floats && !d->spectrum_data))
+        return fail(PYR_ERR_INVALID_ARGUMENT, "null table with a non-zero count");
     for (uint32_t i = 0; i < d->num_instrs; ++i) {
         const PyrInstr& ins = d->instrs[i];
         if (ins.op == PYR_OP_COLOR_TEXTURE || ins.op == PYR_OP_MONO_TEXTURE) {
@@ -76,6 +81,10 @@ int validate(const PyrSceneDesc* d) {
         const PyrSpectrum& s = d->spectra[i];
         uint64_t floats = s.format == PYR_SPECTRUM_CURVE ? 2ull * s.count : s.count;
         if (s.offset + floats > d->num_spectrum_floats) return fail(PYR_ERR_INVALID_ARGUMENT, "spectrum data out of range");
+        // Spectrum::get interpolates between samples i and i + 1 for min < w < max (project/spectra.rs:44-54): with one sample
+        // the reference indexes out of bounds and panics; here the description is refused
+        if (s.format == PYR_SPECTRUM_ARRAY && s.count == 1 && s.min < s.max) return fail(PYR_ERR_INVALID_ARGUMENT, "array spectrum with one sample over a non-empty span");
+        if (s.format > PYR_SPECTRUM_CURVE) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown spectrum format");
     }
     for (uint32_t i = 0; i < d->num_textures; ++i) {
         const PyrTexture& t = d->textures[i];
@@ -205,6 +214,11 @@ struct PyrScene {
         if (wf_host_flag) (void)hipHostFree(wf_host_flag);
     }
 };
+
+namespace pyr {
+int api_fail(int code, const std::string& message) { return fail(code, message); }
+int scene_device(const PyrScene* scene) { return scene->device; }
+} // namespace pyr
 
 namespace {
 
@@ -467,12 +481,17 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.num_spectra = d->num_spectra;
     v.num_programs = d->num_programs;
     v.num_spectrum_floats = d->num_spectrum_floats;
+    v.num_materials = d->num_materials;
+    v.num_components = d->num_components;
     {
-        const uint32_t floats = d->num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float)) + d->num_spectrum_floats;
-        // <= 12 KB, and only for scenes too big to live in LDS themselves: a small scene leaves L1 to the tables (C2: staging
-        // them costs a workgroup per CU and is 0.9x), a big one evicts them all the time (C3: staging them is 1.33x)
+        // the small tables the kernels stage into LDS (kernels.hip stage_tables): spectra + the material / component / program /
+        // lamp records. <= 16 KB, and only for scenes too big to live in LDS themselves: a small scene leaves L1 to the tables
+        // (C2: staging the spectra costs a workgroup per CU and is 0.9x), a big one evicts them all the time (C3: 1.33x)
+        const uint64_t floats = (uint64_t)d->num_spectra * (sizeof(PyrSpectrum) / 4) + d->num_spectrum_floats + (uint64_t)d->num_materials * (sizeof(PyrMaterial) / 4) +
+                                (uint64_t)d->num_components * (sizeof(PyrComponent) / 4) + (uint64_t)d->num_programs * (sizeof(DevProgram) / 4) +
+                                (uint64_t)d->num_lamps * (sizeof(DevLamp) / 4);
         const bool big_scene = (size_t)bvh.nodes.size() * 64 + prims.size() * 48 > 8 * 1024;
-        v.lds_table_floats = (floats <= 3072 && big_scene) ? floats : 0;
+        v.lds_table_floats = (floats <= 4096 && big_scene) ? (uint32_t)floats : 0;
     }
     v.needs_interpreter = needs_interpreter ? 1u : 0u;
     v.uses_textures = uses_textures ? 1u : 0u;
@@ -493,8 +512,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
 
 struct TilePlan {
     uint32_t tiles_x = 0, tiles_y = 0;
-    uint32_t chunks_interior = 0, chunks_right = 0, chunks_bottom = 0, chunks_corner = 0;
-    uint32_t chunk_begin = 0, chunk_end = 0; // image-wide chunk numbers of [tile_begin, tile_end)
+    uint32_t tile_begin = 0, tile_stride = 1, tile_count = 0;
+    uint32_t chunks_per_tile = 0;
+    uint32_t chunk_begin = 0, chunk_end = 0; // chunk numbers of the call's tiles (device_scene.h RenderLaunch)
 };
 
 int plan_tiles(const PyrFilmDesc* film, const PyrRenderParams* p, TilePlan& plan) {
@@ -502,27 +522,24 @@ int plan_tiles(const PyrFilmDesc* film, const PyrRenderParams* p, TilePlan& plan
     const uint32_t ts = p->tile_size;
     plan.tiles_x = (film->width + ts - 1) / ts;
     plan.tiles_y = (film->height + ts - 1) / ts;
-    const uint32_t total = plan.tiles_x * plan.tiles_y;
-    const uint32_t begin = p->tile_begin, end = p->tile_end ? p->tile_end : total;
-    if (begin > end || end > total) return fail(PYR_ERR_INVALID_ARGUMENT, "tile range out of bounds");
-    const uint64_t w_last = film->width - (uint64_t)(plan.tiles_x - 1) * ts, h_last = film->height - (uint64_t)(plan.tiles_y - 1) * ts;
-    auto chunks = [&](uint64_t w, uint64_t h) { return (w * h * p->pixel_samples + 63) / 64; }; // iterations: simple.rs:73
-    const uint64_t c_int = chunks(ts, ts), c_right = chunks(w_last, ts), c_bottom = chunks(ts, h_last), c_corner = chunks(w_last, h_last);
-    auto prefix = [&](uint32_t tile) -> uint64_t { // chunks of all tiles before `tile`
-        const uint64_t row = (uint64_t)(plan.tiles_x - 1) * c_int + c_right;
-        uint32_t ty = tile / plan.tiles_x, tx = tile % plan.tiles_x;
-        if (ty < plan.tiles_y - 1) return ty * row + tx * c_int;
-        if (ty == plan.tiles_y - 1) return (uint64_t)(plan.tiles_y - 1) * row + tx * c_bottom;
-        return (uint64_t)(plan.tiles_y - 1) * row + (uint64_t)(plan.tiles_x - 1) * c_bottom + c_corner; // tile == total
-    };
-    if (prefix(total) >= 0xFFFFFFFFull || c_int >= 0xFFFFFFFFull) return fail(PYR_ERR_UNSUPPORTED, "too many samples for one image: more than 2^32 chunks");
-    plan.chunks_interior = (uint32_t)c_int;
-    plan.chunks_right = (uint32_t)c_right;
-    plan.chunks_bottom = (uint32_t)c_bottom;
-    plan.chunks_corner = (uint32_t)c_corner;
-    plan.chunk_begin = (uint32_t)prefix(begin);
-    plan.chunk_end = (uint32_t)prefix(end);
+    const uint64_t total = (uint64_t)plan.tiles_x * plan.tiles_y;
+    const uint64_t begin = p->tile_begin, end = p->tile_end ? p->tile_end : total;
+    if (total >= 0xFFFFFFFFull || begin > end || end > total) return fail(PYR_ERR_INVALID_ARGUMENT, "tile range out of bounds");
+    plan.tile_begin = (uint32_t)begin;
+    plan.tile_stride = std::max(1u, p->tile_stride);
+    plan.tile_count = (uint32_t)((end - begin + plan.tile_stride - 1) / plan.tile_stride);
+    const uint64_t per_tile = ((uint64_t)ts * ts * p->pixel_samples + 63) / 64; // iterations of a full tile: simple.rs:73
+    if (per_tile * plan.tile_count >= 0xFFFFFFFFull) return fail(PYR_ERR_UNSUPPORTED, "too many samples for one call: more than 2^32 chunks");
+    plan.chunks_per_tile = (uint32_t)std::max<uint64_t>(per_tile, 1); // pixel_samples == 0: no chunk at all
+    plan.chunk_begin = 0;
+    plan.chunk_end = (uint32_t)(per_tile * plan.tile_count);
     return PYR_OK;
+}
+
+uint64_t film_buffer_grains(const PyrFilmDesc* film, const PyrRenderParams* p, const TilePlan& plan) {
+    if (p->film_layout == PYR_FILM_TILE_BLOCKS) return (uint64_t)plan.tile_count * (p->tile_size + 2ull) * (p->tile_size + 2ull) * film->bins;
+    const uint32_t rows = p->film_row_count ? p->film_row_count : film->height;
+    return (uint64_t)rows * film->width * film->bins;
 }
 
 int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* p, const void* film_ptr) {
@@ -533,6 +550,9 @@ int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
     uint32_t rows = p->film_row_count ? p->film_row_count : film->height;
     if ((uint64_t)p->film_row_begin + rows > film->height) return fail(PYR_ERR_INVALID_ARGUMENT, "film window exceeds the image");
     if (p->spectrum_samples > 64) return fail(PYR_ERR_UNSUPPORTED, "spectrum_samples > 64");
+    if (p->film_layout > PYR_FILM_TILE_BLOCKS) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown film layout");
+    if (p->film_layout == PYR_FILM_TILE_BLOCKS && (p->film_row_begin || p->film_row_count))
+        return fail(PYR_ERR_INVALID_ARGUMENT, "a film of tile blocks has no row window");
     return PYR_OK;
 }
 
@@ -630,12 +650,13 @@ RenderLaunch make_launch(const PyrCamera* camera, const PyrFilmDesc* film, const
     L.pixel_samples = p->pixel_samples;
     L.tiles_x = plan.tiles_x;
     L.tiles_y = plan.tiles_y;
-    L.chunks_interior = plan.chunks_interior;
-    L.chunks_right = plan.chunks_right;
-    L.chunks_bottom = plan.chunks_bottom;
-    L.chunks_corner = plan.chunks_corner;
+    L.tile_begin = plan.tile_begin;
+    L.tile_stride = plan.tile_stride;
+    L.tile_count = plan.tile_count;
+    L.chunks_per_tile = plan.chunks_per_tile;
     L.chunk_begin = plan.chunk_begin;
     L.chunk_end = plan.chunk_end;
+    L.film_layout = p->film_layout;
     L.film_row_begin = p->film_row_begin;
     L.film_row_count = p->film_row_count ? p->film_row_count : film->height;
     L.seed = p->seed;
@@ -712,8 +733,7 @@ int pyr_render_simple(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
     if ((rc = plan_tiles(film, params, plan)) != PYR_OK) return rc;
     const char* message = "Rendering"; // simple.rs:30
     if (on_status) on_status(user, 0, message);
-    uint32_t rows = params->film_row_count ? params->film_row_count : film->height;
-    size_t bytes = (size_t)rows * film->width * film->bins * sizeof(PyrGrain);
+    const size_t bytes = (size_t)film_buffer_grains(film, params, plan) * sizeof(PyrGrain);
     DeviceBuffer film_dev;
     if ((rc = film_dev.upload(film_inout, bytes)) != PYR_OK) return rc;
     RenderLaunch L = make_launch(camera, film, params, plan);
@@ -738,6 +758,44 @@ int pyr_render_simple(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
         if (on_status) on_status(user, (uint8_t)((sidx + 1) * 100 / slices), message);
     }
     HIP_TRY(hipMemcpy(film_inout, film_dev.ptr, bytes, hipMemcpyDeviceToHost));
+    return PYR_OK;
+}
+
+uint64_t pyr_film_blocks_grains(const PyrFilmDesc* film, const PyrRenderParams* params) {
+    if (!film || !params || film->width == 0 || film->height == 0 || film->bins == 0 || params->tile_size == 0) {
+        fail(PYR_ERR_INVALID_ARGUMENT, "zero-sized parameter");
+        return 0;
+    }
+    TilePlan plan;
+    PyrRenderParams p = *params;
+    if (p.pixel_samples == 0) p.pixel_samples = 1; // the size does not depend on it
+    if (plan_tiles(film, &p, plan) != PYR_OK) return 0;
+    p.film_layout = PYR_FILM_TILE_BLOCKS;
+    return film_buffer_grains(film, &p, plan);
+}
+
+int pyr_film_blocks_assemble_device(const PyrFilmDesc* film, const PyrRenderParams* params, const PyrGrain* blocks_device, PyrGrain* film_device, int device,
+                                    void* hip_stream) {
+    if (!film || !params || !blocks_device || !film_device) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    if (film->width == 0 || film->height == 0 || film->bins == 0 || params->tile_size == 0) return fail(PYR_ERR_INVALID_ARGUMENT, "zero-sized parameter");
+    if (pyr_device_count() <= device || device < 0) return fail(PYR_ERR_DEVICE, "no such HIP device; pyrite_gpu has no CPU path");
+    TilePlan plan;
+    PyrRenderParams p = *params;
+    if (p.pixel_samples == 0) p.pixel_samples = 1;
+    int rc = plan_tiles(film, &p, plan);
+    if (rc != PYR_OK) return rc;
+    HIP_TRY(hipSetDevice(device));
+    AssembleLaunch A{};
+    A.film = *film;
+    A.tile_size = params->tile_size;
+    A.tiles_x = plan.tiles_x;
+    A.tile_begin = plan.tile_begin;
+    A.tile_stride = plan.tile_stride;
+    A.tile_count = plan.tile_count;
+    A.blocks = blocks_device;
+    A.film_out = film_device;
+    rc = launch_assemble(A, hip_stream);
+    if (rc != PYR_OK) return fail(rc, kernels_last_error());
     return PYR_OK;
 }
 
@@ -817,7 +875,13 @@ static int develop_common(const PyrFilmDesc* film, const PyrGrain* grains_device
         std::memcpy(host.data() + 2 * n, p->white_mul, n * 4);
     }
     std::memcpy(host.data() + 3 * n, p->xyz_table, 3 * (size_t)p->xyz_count * 4);
-    HIP_TRY(hipMemcpy(tables, host.data(), floats * sizeof(float), hipMemcpyHostToDevice)); // synchronous: `host` dies with this frame
+    {
+        const hipError_t copied = hipMemcpy(tables, host.data(), floats * sizeof(float), hipMemcpyHostToDevice); // synchronous: `host` dies with this frame
+        if (copied != hipSuccess) {
+            (void)hipFreeAsync(tables, stream);
+            return hip_fail(copied, "hipMemcpy(development tables)");
+        }
+    }
     DevelopLaunch D{};
     D.film = *film;
     D.grains = grains_device;

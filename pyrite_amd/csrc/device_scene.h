@@ -90,7 +90,8 @@ struct DevScene {
     uint32_t num_nodes, num_prims;
     uint32_t num_spectra, num_spectrum_floats;
     uint32_t num_programs;
-    uint32_t lds_table_floats; // > 0: the spectrum tables are staged into LDS (this many floats)
+    uint32_t num_materials, num_components;
+    uint32_t lds_table_floats; // > 0: spectra, materials, components, programs and lamps are staged into LDS (this many floats in all)
     // texture space (interpreter builds only)
     const float* tri_tex;          // DevTriTex[] by original triangle index, or nullptr
     const float* sphere_tex_scale; // [n][2]
@@ -108,11 +109,14 @@ struct RenderLaunch {
     PyrFilmDesc film;
     uint32_t bounces, light_samples, spectrum_samples, tile_size, pixel_samples;
     uint32_t tiles_x, tiles_y;
-    // A chunk is 64 consecutive iterations of one tile. Chunks are numbered over the whole image in raster tile order;
-    // every tile of a row has chunks_interior chunks except the last column (chunks_right); the last tile row uses
-    // chunks_bottom / chunks_corner. [chunk_begin, chunk_end) is the range this launch renders.
-    uint32_t chunks_interior, chunks_right, chunks_bottom, chunks_corner;
+    // The launch renders the tiles tile_begin + k * tile_stride (k = 0 .. tile_count - 1) of the raster grid. A chunk is 64
+    // consecutive iterations of one tile; every tile owns chunks_per_tile chunk numbers (the count a full tile_size^2 tile
+    // needs: tiles cut by the image border leave their last ones empty), so chunk c belongs to the launch's tile
+    // c / chunks_per_tile. [chunk_begin, chunk_end) is the range this launch renders (progress slices cut it).
+    uint32_t tile_begin, tile_stride, tile_count;
+    uint32_t chunks_per_tile;
     uint32_t chunk_begin, chunk_end;
+    uint32_t film_layout; // PYR_FILM_ROWS: film_out holds pixel rows [film_row_begin, + film_row_count); PYR_FILM_TILE_BLOCKS: one ringed block per tile
     uint32_t film_row_begin, film_row_count;
     uint64_t seed;
     float grains_per_wavelength; // bins / wl_width (film.rs:38)
@@ -169,6 +173,16 @@ struct DevelopLaunch {
     uint8_t* rgb_out; // device
 };
 int launch_develop(const DevelopLaunch& launch, void* stream);
+
+// Adds the PYR_FILM_TILE_BLOCKS buffer of the tiles tile_begin + k * tile_stride (k < tile_count) into a whole-image film.
+struct AssembleLaunch {
+    PyrFilmDesc film;
+    uint32_t tile_size, tiles_x;
+    uint32_t tile_begin, tile_stride, tile_count;
+    const PyrGrain* blocks; // device
+    PyrGrain* film_out;     // device, whole image
+};
+int launch_assemble(const AssembleLaunch& launch, void* stream);
 
 // launchers (kernels.hip)
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);

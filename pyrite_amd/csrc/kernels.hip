@@ -1120,35 +1120,47 @@ DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
     return ls;
 }
 
-// Pixel a view-plane position exposes to (AspectRatio::to_pixel, film.rs:233-246 + Film::get_pixel :51-54), as the index
-// of its first grain inside the film window, or -1 when the position maps outside the image / the window.
-DEV long long film_pixel_base(const RenderLaunch& L, float px, float py) {
+// Pixel a view-plane position exposes to (AspectRatio::to_pixel, film.rs:233-246 + Film::get_pixel :51-54), as the index of
+// the pixel inside the launch's film buffer, or PIXEL_NONE when the position maps outside the image / the buffer. It depends
+// on the sample's view-plane position alone, so it is worked out once when the sample starts. PYR_FILM_ROWS: the buffer holds
+// whole pixel rows; PYR_FILM_TILE_BLOCKS: one (tile_size + 2)^2 block per tile of the launch, the tile's pixels with a ring
+// of one pixel around them (pyrite_gpu.h).
+constexpr uint32_t PIXEL_NONE = 0xFFFFFFFFu;
+DEV uint32_t film_pixel(const RenderLaunch& L, uint32_t tile, float px, float py) {
     const uint32_t width = L.film.width, height = L.film.height;
     uint32_t x, y;
     if (width >= height) {
         float size = (float)width, ratio = __fdiv_rn((float)height, (float)width);
-        if (!(fabsf(py) <= ratio)) return -1;
+        if (!(fabsf(py) <= ratio)) return PIXEL_NONE;
         x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, 1.0f)), 0.5f));
         y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, ratio)), 0.5f));
     } else {
         float size = (float)height, ratio = __fdiv_rn((float)width, (float)height);
-        if (!(fabsf(px) <= ratio)) return -1;
+        if (!(fabsf(px) <= ratio)) return PIXEL_NONE;
         x = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(px, ratio)), 0.5f));
         y = f32_as_index(__fmul_rn(__fmul_rn(size, __fadd_rn(py, 1.0f)), 0.5f));
     }
-    if (x >= width || y >= height) return -1;
-    if (y < L.film_row_begin || y >= L.film_row_begin + L.film_row_count) return -1;
-    return (long long)(((size_t)x + (size_t)(y - L.film_row_begin) * width) * L.film.bins);
+    if (x >= width || y >= height) return PIXEL_NONE;
+    if (L.film_layout == PYR_FILM_TILE_BLOCKS) {
+        const uint32_t ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
+        const uint32_t side = L.tile_size + 2u;
+        const uint32_t bx = x + 1u - tx * L.tile_size, by = y + 1u - ty * L.tile_size; // wraps to a huge value left of / above the ring
+        if (bx >= side || by >= side) return PIXEL_NONE;
+        const uint32_t block = (tile - L.tile_begin) / L.tile_stride;
+        return (block * side + by) * side + bx;
+    }
+    if (y < L.film_row_begin || y >= L.film_row_begin + L.film_row_count) return PIXEL_NONE;
+    return x + (y - L.film_row_begin) * width;
 }
 
 // Film::expose (film.rs:89-95) into a known pixel: wavelength_to_grain (:85-87) + Grain::increment (:145-162) as two
 // no-return float atomics (the reference's 5-try CAS may drop samples under contention; atomics never do).
 template <bool COUNT>
-DEV void expose_grain(const RenderLaunch& L, long long pixel_base, float wavelength, float brightness, Counters& cnt) {
-    if (pixel_base < 0) return;
+DEV void expose_grain(const RenderLaunch& L, uint32_t pixel, float wavelength, float brightness, Counters& cnt) {
+    if (pixel == PIXEL_NONE) return;
     uint32_t grain = f32_as_index(__fmul_rn(__fsub_rn(wavelength, L.film.wl_start), L.grains_per_wavelength));
     grain = grain < L.film.bins - 1 ? grain : L.film.bins - 1;
-    float* g = reinterpret_cast<float*>(L.film_out + pixel_base + grain);
+    float* g = reinterpret_cast<float*>(L.film_out + ((size_t)pixel * L.film.bins + grain));
     atomicAdd(g, brightness); // value * weight with weight == 1 (simple.rs:95-98)
     atomicAdd(g + 1, 1.0f);
     if (COUNT) cnt.exposures++;
@@ -1157,7 +1169,7 @@ DEV void expose_grain(const RenderLaunch& L, long long pixel_base, float wavelen
 // Register-resident state of one path (the hero wavelength; the S-1 companions live in LDS, see Spectral).
 struct Path {
     Rng rng;
-    float px, py;
+    uint32_t pixel; // film_pixel of the sample's view-plane position
     f3 o, d;
     float wl, bright, refl;
     uint32_t bounce, events; // bounces made; light_sample_events (tracer.rs:219)
@@ -1203,13 +1215,28 @@ DEV DevScene stage_tables(const DevScene& S, float* lds, uint32_t lds_floats_bef
     DevScene local = S;
     if (TABLES == 1 || (TABLES == -1 && S.lds_table_floats != 0)) {
         float* dst = lds + lds_floats_before;
-        const uint32_t rec_floats = S.num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float));
-        const float* rec_src = reinterpret_cast<const float*>(S.spectra);
-        for (uint32_t i = threadIdx.x; i < rec_floats; i += BLOCK) dst[i] = rec_src[i];
-        for (uint32_t i = threadIdx.x; i < S.num_spectrum_floats; i += BLOCK) dst[rec_floats + i] = S.spectrum_data[i];
+        auto stage = [&](const void* src, uint32_t floats) {
+            const float* from = reinterpret_cast<const float*>(src);
+            for (uint32_t i = threadIdx.x; i < floats; i += BLOCK) dst[i] = from[i];
+            float* at = dst;
+            dst += floats;
+            return at;
+        };
+        local.spectra = reinterpret_cast<const PyrSpectrum*>(stage(S.spectra, S.num_spectra * (uint32_t)(sizeof(PyrSpectrum) / sizeof(float))));
+        local.spectrum_data = stage(S.spectrum_data, S.num_spectrum_floats);
+#ifndef PYR_LDS_SMALL_TABLES
+#define PYR_LDS_SMALL_TABLES 1
+#endif
+#if PYR_LDS_SMALL_TABLES
+        // The records a bounce walks through one after the other -- material -> component -> program, and the lamp of a
+        // next-event estimation -- are a few hundred bytes per scene, but every step of that chain was an L2 round trip (the
+        // BVH traffic keeps evicting them from L1) in phases that run at a third of the wave's width: staged with the spectra.
+        local.materials = reinterpret_cast<const PyrMaterial*>(stage(S.materials, S.num_materials * (uint32_t)(sizeof(PyrMaterial) / sizeof(float))));
+        local.components = reinterpret_cast<const PyrComponent*>(stage(S.components, S.num_components * (uint32_t)(sizeof(PyrComponent) / sizeof(float))));
+        local.programs = reinterpret_cast<const DevProgram*>(stage(S.programs, S.num_programs * (uint32_t)(sizeof(DevProgram) / sizeof(float))));
+        local.lamps = reinterpret_cast<const DevLamp*>(stage(S.lamps, S.num_lamps * (uint32_t)(sizeof(DevLamp) / sizeof(float))));
+#endif
         __syncthreads();
-        local.spectra = reinterpret_cast<const PyrSpectrum*>(dst);
-        local.spectrum_data = dst + rec_floats;
     }
     return local;
 }
@@ -1220,12 +1247,13 @@ DEV void start_sample(const RenderLaunch& L, uint32_t tile, uint64_t iteration, 
     const uint32_t SS = L.spectrum_samples;
     p.rng = rng_seed(L.seed, tile, iteration);
     // Tile::sample_point, renderer/algorithm.rs:113-119 (unfused: decides the pixel)
-    p.px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(p.rng)));
-    p.py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(p.rng)));
+    const float px = __fadd_rn(area.from_x, __fmul_rn(area.size_x, rng_f32(p.rng)));
+    const float py = __fadd_rn(area.from_y, __fmul_rn(area.size_y, rng_f32(p.rng)));
+    p.pixel = film_pixel(L, tile, px, py);
     // Camera::ray_towards, cameras.rs:70-97
     {
-        float focus_x = p.px / L.camera.view_plane * L.camera.focus_distance;
-        float focus_y = p.py / L.camera.view_plane * L.camera.focus_distance;
+        float focus_x = px / L.camera.view_plane * L.camera.focus_distance;
+        float focus_y = py / L.camera.view_plane * L.camera.focus_distance;
         f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
         f3 origin = mk(0, 0, 0), direction = target;
         if (L.camera.aperture > 0.0f) {
@@ -1263,27 +1291,16 @@ DEV void start_sample(const RenderLaunch& L, uint32_t tile, uint64_t iteration, 
     p.bounce = 0;
 }
 
-// Maps an image-wide chunk number to (tile, first iteration, tile rectangle). Returns false when the lane's iteration lies
-// beyond the tile's iteration count (last chunk of a tile).
+// Maps a chunk number of the launch to (tile, first iteration, tile rectangle): chunk c belongs to the launch's
+// (c / chunks_per_tile)-th tile. Returns false when the lane's iteration lies beyond the tile's iteration count (the last
+// chunk of a tile, and the empty chunk numbers of a tile cut by the image border).
 DEV bool locate_chunk(const RenderLaunch& L, uint32_t chunk, uint32_t lane, uint32_t& tile, uint64_t& iteration, TileArea& area) {
-    const uint32_t row_chunks = (L.tiles_x - 1) * L.chunks_interior + L.chunks_right;
-    const uint32_t full_rows = L.tiles_y - 1;
-    uint32_t ty, r, per_tile;
-    if (chunk < full_rows * row_chunks) {
-        ty = chunk / row_chunks;
-        r = chunk - ty * row_chunks;
-        per_tile = L.chunks_interior;
-    } else {
-        ty = full_rows;
-        r = chunk - full_rows * row_chunks;
-        per_tile = L.chunks_bottom;
-    }
-    uint32_t tx = min(r / per_tile, L.tiles_x - 1);
-    uint32_t within = r - tx * per_tile;
-    tile = ty * L.tiles_x + tx;
-    uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
-    uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
-    uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
+    const uint32_t k = chunk / L.chunks_per_tile, within = chunk - k * L.chunks_per_tile;
+    tile = L.tile_begin + k * L.tile_stride;
+    const uint32_t ty = tile / L.tiles_x, tx = tile - ty * L.tiles_x;
+    const uint32_t sx = tx * L.tile_size, sy = ty * L.tile_size;
+    const uint32_t w = min(L.film.width - sx, L.tile_size), h = min(L.film.height - sy, L.tile_size);
+    const uint64_t iterations = (uint64_t)w * h * L.pixel_samples;
     iteration = (uint64_t)within * 64u + lane;
     if (iteration >= iterations) return false;
     area = to_view_area(sx, sy, w, h, L.film.width, L.film.height);
@@ -1518,10 +1535,9 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
 // simple.rs:133-139: expose the hero always, the companions unless a bounce dispersed.
 template <bool COUNT>
 DEV void finish_path(const RenderLaunch& L, const Path& p, Spectral& spec, Counters& cnt) {
-    const long long pixel_base = film_pixel_base(L, p.px, p.py);
-    expose_grain<COUNT>(L, pixel_base, p.wl, p.bright, cnt);
+    expose_grain<COUNT>(L, p.pixel, p.wl, p.bright, cnt);
     if (p.use_additional)
-        for (uint32_t k = 0; k + 1 < L.spectrum_samples; ++k) expose_grain<COUNT>(L, pixel_base, spec.wl(k), spec.bright(k), cnt);
+        for (uint32_t k = 0; k + 1 < L.spectrum_samples; ++k) expose_grain<COUNT>(L, p.pixel, spec.wl(k), spec.bright(k), cnt);
 }
 
 // Bounce-synchronous integrator: a wave takes a chunk of 64 samples and walks the 64 paths bounce by bounce. Next-event
@@ -1615,7 +1631,10 @@ enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EX
 
 struct Trav { // resumable World::intersect
     f3 o, d, inv;
-    float limit, limit_cull, closest;
+    // `closest` is the distance boxes are cut off at: the closest hit so far for an extension ray; for a shadow ray the square
+    // root of the blocking limit with its 0.1 % margin (traverse<>'s limit_cull) -- one comparison serves both kinds of ray, and
+    // the half-ulp of the root is far inside that margin. A shadow ray never reads it as a hit distance.
+    float limit, closest;
     int node, sp;
     uint32_t shape;
     float u, v;
@@ -1623,9 +1642,10 @@ struct Trav { // resumable World::intersect
 };
 
 // Puts a query whose ray, limit and plane results are set at the root of the tree.
+DEV float shadow_cutoff(float limit) { return sqrtf(limit * 1.001f + 1.0e-3f); } // +inf stays +inf; a negative limit gives NaN: nothing passes
 DEV void trav_restart(Trav& t) {
     t.inv = box_reciprocal(t.d);
-    t.limit_cull = t.limit * 1.001f + 1.0e-3f;
+    if (t.shadow) t.closest = shadow_cutoff(t.limit);
     t.blocked = false;
     t.node = 0;
     t.sp = 0;
@@ -1639,7 +1659,6 @@ DEV bool trav_begin(const DevScene& S, Trav& t, f3 o, f3 d, bool shadow, float l
     t.shadow = shadow;
     t.blocked = false;
     t.limit = limit;
-    t.limit_cull = limit * 1.001f + 1.0e-3f;
     t.closest = PYR_INF;
     t.shape = PYR_HIT_NONE;
     t.u = t.v = 0.0f;
@@ -1668,8 +1687,9 @@ DEV bool trav_begin(const DevScene& S, Trav& t, f3 o, f3 d, bool shadow, float l
 // levels in the lane's scratch. A SAH tree over 819 k triangles is ~30 levels deep but a ray rarely holds more than a
 // dozen pending subtrees, so a short LDS part keeps the LDS footprint (and with it the waves per CU) independent of the
 // tree's worst-case depth while the deep end is touched by a few rays only.
+typedef __attribute__((address_space(3))) int lds_int;
 struct TravStack {
-    int* lds; // + threadIdx.x
+    lds_int* lds; // + threadIdx.x; an LDS pointer by type: a generic one makes every push and pop a flat_ access that drains both counters
     int lds_entries;
     int deep[kMaxStackDepth];
     DEV void push(int sp, int value) {
@@ -1686,9 +1706,8 @@ struct TravStack {
 // the children that are hit are ordered by entry distance with a five-comparator network, the nearest is entered and the
 // others are pushed far to near, so they pop nearest first. Returns true when the traversal has finished.
 template <bool COUNT>
-DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    const float4* nd = view.nodes + 8 * (size_t)t.node;
-    const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5], ch = nd[6];
+DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, Trav& t,
+                         TravStack& stack, Counters& cnt) {
     const f2v ix = {t.inv.x, t.inv.x}, iy = {t.inv.y, t.inv.y}, iz = {t.inv.z, t.inv.z};
     const float ox = -(t.o.x * t.inv.x), oy = -(t.o.y * t.inv.y), oz = -(t.o.z * t.inv.z);
     const f2v nox = {ox, ox}, noy = {oy, oy}, noz = {oz, oz};
@@ -1703,15 +1722,17 @@ DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counte
         const f2v blz = __builtin_elementwise_fma((f2v){lz.z, lz.w}, iz, noz), bhz = __builtin_elementwise_fma((f2v){hz.z, hz.w}, iz, noz);
         const float tl[4][3] = {{alx.x, aly.x, alz.x}, {alx.y, aly.y, alz.y}, {blx.x, bly.x, blz.x}, {blx.y, bly.y, blz.y}};
         const float th[4][3] = {{ahx.x, ahy.x, ahz.x}, {ahx.y, ahy.y, ahz.y}, {bhx.x, bhy.x, bhz.x}, {bhx.y, bhy.y, bhz.y}};
+        // no branches in here: the backend knows an fma result is never a signalling NaN only inside one basic block, and quiets
+        // every min / max operand again (a v_max x, x, x each) on the far side of one
         for (int k = 0; k < 4; ++k) {
             const float tmin = fmaxf(fmaxf(fminf(tl[k][0], th[k][0]), fminf(tl[k][1], th[k][1])), fminf(tl[k][2], th[k][2]));
             const float tmax = fminf(fminf(fmaxf(tl[k][0], th[k][0]), fmaxf(tl[k][1], th[k][1])), fmaxf(tl[k][2], th[k][2]));
             const float entry = fmaxf(tmin, 0.0f);
-            bool hit = tmax >= tmin && tmax >= 0.0f && c[k] != INT32_MIN;
-            if (COUNT) cnt.box_tests += c[k] != INT32_MIN ? 1u : 0u;
-            hit = hit && (t.shadow ? entry * entry < t.limit_cull : entry < t.closest);
+            const bool present = c[k] != INT32_MIN;
+            if (COUNT) cnt.box_tests += present ? 1u : 0u;
+            const bool hit = (tmax >= tmin) & (tmax >= 0.0f) & present & (entry < t.closest);
             e[k] = hit ? entry : PYR_INF; // misses sort last
-            if (!hit) c[k] = INT32_MIN;
+            c[k] = hit ? c[k] : INT32_MIN;
         }
     }
     // order (e, c) ascending: network (0,1) (2,3) (0,2) (1,3) (1,2)
@@ -1738,6 +1759,88 @@ DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counte
     t.node = c[0];
     return false;
 }
+template <bool COUNT>
+DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
+    const float4* nd = view.nodes + 8 * (size_t)t.node;
+    return wide_node_visit<COUNT>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
+}
+
+// One primitive of a leaf, its record already loaded (a, b, c = the three vectors of a DevPrim): the tests and the
+// bookkeeping of trav_step's leaf part. `first` / `count` are the leaf code's fields. Returns true when the traversal has finished.
+template <bool COUNT>
+DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_t first, uint32_t count, Trav& t, TravStack& stack, Counters& cnt) {
+    const uint32_t shape = __float_as_uint(a.w);
+    float dist, u = 0.0f, v = 0.0f;
+    bool ok;
+    if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
+        if (COUNT) cnt.triangle_tests++;
+        ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t.o, t.d, dist, u, v);
+    } else {
+        f3 point;
+        if (COUNT) cnt.sphere_tests++;
+        ok = sphere_box_guard(mk(a.x, a.y, a.z), b.x, t.o, t.d, t.closest, t.shadow) && sphere_test(mk(a.x, a.y, a.z), b.x, t.o, t.d, dist, point);
+    }
+    if (ok) {
+        if (t.shadow) {
+            if (dist > DIST_EPSILON && dist * dist < t.limit) {
+                t.blocked = true;
+                return true;
+            }
+        } else if (dist > DIST_EPSILON && dist < t.closest) {
+            t.closest = dist;
+            t.shape = shape;
+            t.u = u;
+            t.v = v;
+        }
+    }
+    if (count > 1) {
+        t.node = -1 - (int)(((first + 1) << 3) | (count - 1));
+        return false;
+    }
+    if (t.sp == 0) return true;
+    t.sp--;
+    t.node = stack.pop(t.sp);
+    return false;
+}
+
+// One step of every lane that has a ray in flight, whichever kind it waits for, on ONE memory round trip: a lane at an inner
+// node needs the node's seven vectors, a lane in a leaf the primitive's three; all lanes issue their first three loads
+// together (the address differs, the instruction is the same), the node lanes their other four right behind, and only then
+// does anybody wait. The node arithmetic and the primitive test still run one after the other at partial occupancy, but the
+// round trip -- which is what a step costs (21.9 k cycles per 8-step turn on C3 against ~600 cycles of issue) -- is paid once
+// per step instead of once per kind, and no lane sits a step out as under the node / leaf vote. Wide trees only.
+template <bool COUNT>
+DEV bool trav_step_unified(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
+    const bool at_node = active && t.node >= 0;
+    const uint32_t code = (uint32_t)(-1 - t.node);
+    const uint32_t first = code >> 3, count = code & 7u;
+    const bool at_prim = active && t.node < 0 && count != 0;
+    const float4* addr = at_node ? view.nodes + 8 * (size_t)t.node : view.prims + 3 * (size_t)first;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0;
+    if (at_node || at_prim) {
+        r0 = addr[0];
+        r1 = addr[1];
+        r2 = addr[2];
+    }
+    if (at_node) {
+        r3 = addr[3];
+        r4 = addr[4];
+        r5 = addr[5];
+        r6 = addr[6];
+    }
+    bool done = false;
+    if (at_node) done = wide_node_visit<COUNT>(r0, r1, r2, r3, r4, r5, r6, t, stack, cnt);
+    if (at_prim) done = leaf_prim_visit<COUNT>(r0, r1, r2, first, count, t, stack, cnt);
+    if (active && !at_node && !at_prim) { // an empty leaf: nothing to test
+        if (t.sp == 0) {
+            done = true;
+        } else {
+            t.sp--;
+            t.node = stack.pop(t.sp);
+        }
+    }
+    return done;
+}
 
 template <bool COUNT>
 DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
@@ -1748,14 +1851,7 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
         if (COUNT) cnt.box_tests += 2;
         float e0, e1;
         slab_pair(n0, n1, n2, t.o, t.inv, e0, e1);
-        bool h0, h1;
-        if (t.shadow) {
-            h0 = e0 >= 0.0f && e0 * e0 < t.limit_cull;
-            h1 = e1 >= 0.0f && e1 * e1 < t.limit_cull;
-        } else {
-            h0 = e0 >= 0.0f && e0 < t.closest;
-            h1 = e1 >= 0.0f && e1 < t.closest;
-        }
+        const bool h0 = (e0 >= 0.0f) & (e0 < t.closest), h1 = (e1 >= 0.0f) & (e1 < t.closest);
         const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
         if (h0 && h1) {
             const bool swap = e1 < e0;
@@ -1825,8 +1921,12 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
 #ifndef PYR_VOTE_BOTH
 #define PYR_VOTE_BOTH 65
 #endif
+#ifndef PYR_UNIFIED_FETCH
+#define PYR_UNIFIED_FETCH 0
+#endif
 template <bool COUNT>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
+    if (PYR_UNIFIED_FETCH && view.wide) return trav_step_unified<COUNT>(view, t, stack, cnt, active);
     if (PYR_VOTE_BOTH > 0) {
         const int want_node = __popcll(__ballot(active && t.node >= 0)), want_leaf = __popcll(__ballot(active && t.node < 0));
         const bool run_node = want_node >= want_leaf || want_node >= PYR_VOTE_BOTH;
@@ -2189,7 +2289,8 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         const uint32_t rank = active ? i / SS : 0u, k = active ? i - rank * SS : 0u;
         const uint32_t src = wave_list[rank];
         const uint32_t ops = (uint32_t)__shfl((int)n_ops, (int)src);
-        const float px = __shfl(p.px, (int)src), py = __shfl(p.py, (int)src), hero_wl = __shfl(p.wl, (int)src);
+        const uint32_t pixel = (uint32_t)__shfl((int)p.pixel, (int)src);
+        const float hero_wl = __shfl(p.wl, (int)src);
         const bool use_additional = __shfl((int)p.use_additional, (int)src) != 0;
         const bool hero = k == SS - 1;
         const bool run = active && (hero || use_additional);
@@ -2292,9 +2393,9 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
             }
         }
 #ifdef PYR_REPLAY_NOEXPOSE
-        if (run && bright == 123.456f) expose_grain<COUNT>(L, film_pixel_base(L, px, py), wl, bright, cnt);
+        if (run && bright == 123.456f) expose_grain<COUNT>(L, pixel, wl, bright, cnt);
 #else
-        if (run) expose_grain<COUNT>(L, film_pixel_base(L, px, py), wl, bright, cnt);
+        if (run) expose_grain<COUNT>(L, pixel, wl, bright, cnt);
 #endif
     }
     __builtin_amdgcn_wave_barrier();
@@ -2309,7 +2410,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
     // LDS rows of 256 floats: TAPE: S wavelengths + one row of per-wave lane lists; else wavelengths / brightness / reflectance
     const uint32_t spectral_rows = TAPE ? SS + 1 + kTapeEagerSlots : 3 * SS;
     TravStack stack;
-    stack.lds = reinterpret_cast<int*>(lds + spectral_rows * BLOCK) + threadIdx.x;
+    stack.lds = (lds_int*)(reinterpret_cast<int*>(lds + spectral_rows * BLOCK) + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
     const uint32_t lds_base_floats = (spectral_rows + L.stack_lds) * BLOCK;
@@ -2440,7 +2541,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectLaunch L) {
     extern __shared__ int lds_stack[];
     TravStack stack;
-    stack.lds = lds_stack + threadIdx.x;
+    stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
     const SceneView view = S.wide_nodes ? SceneView{reinterpret_cast<const float4*>(S.wide_nodes), reinterpret_cast<const float4*>(S.prims), true}
@@ -2511,7 +2612,7 @@ DEV f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
 // State groups (float4 each, [group][slot]):
 //   0 chunk | bounce, events, flags | nee_lamp | nee_i        6 closest, shape, u, v (planes' result in, hit out)
 //   1 rng                                                     7 b_position     8 b_normal     9 b_out     10 b_nff
-//   2 px, py, wl, bright                                      11 ls_normal (+ ls_ty; ls_tx rides in 10.w)
+//   2 pixel, -, wl, bright                                    11 ls_normal (+ ls_ty; ls_tx rides in 10.w)
 //   3 refl, nee_probability, ls_scale, ls_color
 //   4 ray origin, limit        5 ray direction, ls_material
 // A visit loads what its entry stage reads (a path coming back from an extension ray does not need the light-sample
@@ -2538,7 +2639,7 @@ DEV void wf_load(const WfPool& P, uint32_t slot, uint32_t word, bool planes, Wal
     w.nee_lamp = __float_as_uint(g0.z);
     w.nee_i = __float_as_uint(g0.w);
     w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
-    w.p.px = g2.x, w.p.py = g2.y, w.p.wl = g2.z, w.p.bright = g2.w;
+    w.p.pixel = __float_as_uint(g2.x), w.p.wl = g2.z, w.p.bright = g2.w;
     w.p.refl = g3.x, w.nee_probability = g3.y, w.ls_scale = g3.z, w.ls_color = __float_as_uint(g3.w);
     w.t.d = xyz(g5), w.ls_material = __float_as_uint(g5.w);
     if (w.stage == ST_NEE) {
@@ -2574,7 +2675,7 @@ DEV void wf_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUN
     P.stage[slot] = w.stage | (w.t.shadow ? WF_SHADOW : 0u);
     if (w.stage == ST_DONE) return;
     g[1 * n] = make_float4(__uint_as_float(w.p.rng.x), __uint_as_float(w.p.rng.y), __uint_as_float(w.p.rng.z), __uint_as_float(w.p.rng.w));
-    g[2 * n] = make_float4(w.p.px, w.p.py, w.p.wl, w.p.bright);
+    g[2 * n] = make_float4(__uint_as_float(w.p.pixel), 0.0f, w.p.wl, w.p.bright);
     g[3 * n] = make_float4(w.p.refl, w.nee_probability, w.ls_scale, __uint_as_float(w.ls_color));
     g[4 * n] = mk4(w.t.o, w.t.limit);
     g[5 * n] = mk4(w.t.d, __uint_as_float(w.ls_material));
@@ -2665,7 +2766,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, uint32_t reserve, uint32_t stack_lds, unsigned long long* counters) {
     extern __shared__ int lds_stack[];
     TravStack stack;
-    stack.lds = lds_stack + threadIdx.x;
+    stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)stack_lds;
     Counters cnt{};
     const SceneView view = S.wide_nodes ? SceneView{reinterpret_cast<const float4*>(S.wide_nodes), reinterpret_cast<const float4*>(S.prims), true}
@@ -2804,6 +2905,78 @@ int launch_develop(const DevelopLaunch& launch, void* stream) {
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         g_kernel_error = std::string("develop kernel launch: ") + hipGetErrorString(err);
+        return PYR_ERR_DEVICE;
+    }
+    return PYR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ film blocks -> film
+// Rank 0's side of the multi-GPU gather: the blocks a rank rendered (PYR_FILM_TILE_BLOCKS: the tile's pixels plus a ring of
+// one pixel) are added into the whole-image film. The pixels of a tile belong to one block of the set only, so they are
+// plain read-modify-writes, one grain (8 bytes) per thread, contiguous along a pixel row in both buffers: HBM-bound, two
+// reads and one write of 8 B per grain. Ring pixels lie inside neighbouring tiles -- which may be in the same set -- so
+// they go second, as atomics, and only where something was exposed (about one sample in 1e6 lands there).
+__global__ __launch_bounds__(BLOCK) void assemble_interior_kernel(AssembleLaunch A) {
+    const uint32_t ts = A.tile_size, side = ts + 2u, bins = A.film.bins;
+    const uint64_t row_grains = (uint64_t)ts * bins, tile_grains = row_grains * ts, total = tile_grains * A.tile_count;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t k = (uint32_t)(i / tile_grains);
+        const uint64_t r = i - (uint64_t)k * tile_grains;
+        const uint32_t row = (uint32_t)(r / row_grains), in_row = (uint32_t)(r - (uint64_t)row * row_grains);
+        const uint32_t col = in_row / bins, bin = in_row - col * bins;
+        const uint32_t tile = A.tile_begin + k * A.tile_stride;
+        const uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+        const uint32_t x = tx * ts + col, y = ty * ts + row;
+        if (x >= A.film.width || y >= A.film.height) continue; // a tile cut by the image border
+        const PyrGrain g = A.blocks[(((size_t)k * side + row + 1u) * side + col + 1u) * bins + bin];
+        PyrGrain* out = A.film_out + ((size_t)x + (size_t)y * A.film.width) * bins + bin;
+        PyrGrain f = *out;
+        f.acc += g.acc;
+        f.weight += g.weight;
+        *out = f;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void assemble_ring_kernel(AssembleLaunch A) {
+    const uint32_t ts = A.tile_size, side = ts + 2u, bins = A.film.bins;
+    const uint32_t ring = 4u * (ts + 1u); // pixels of the ring
+    const uint64_t tile_grains = (uint64_t)ring * bins, total = tile_grains * A.tile_count;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t k = (uint32_t)(i / tile_grains);
+        const uint32_t r = (uint32_t)(i - (uint64_t)k * tile_grains);
+        const uint32_t q = r / bins, bin = r - q * bins;
+        // ring pixel q: top row (side pixels), bottom row (side), then the left and right columns without their corners
+        uint32_t bx, by;
+        if (q < side)
+            bx = q, by = 0u;
+        else if (q < 2u * side)
+            bx = q - side, by = side - 1u;
+        else if (q < 2u * side + ts)
+            bx = 0u, by = q - 2u * side + 1u;
+        else
+            bx = side - 1u, by = q - 2u * side - ts + 1u;
+        const PyrGrain g = A.blocks[(((size_t)k * side + by) * side + bx) * bins + bin];
+        if (g.acc == 0.0f && g.weight == 0.0f) continue;
+        const uint32_t tile = A.tile_begin + k * A.tile_stride;
+        const uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+        const uint32_t x = tx * ts + bx - 1u, y = ty * ts + by - 1u; // wraps for the ring left of / above the image
+        if (x >= A.film.width || y >= A.film.height) continue;
+        float* out = reinterpret_cast<float*>(A.film_out + ((size_t)x + (size_t)y * A.film.width) * bins + bin);
+        atomicAdd(out, g.acc);
+        atomicAdd(out + 1, g.weight);
+    }
+}
+
+int launch_assemble(const AssembleLaunch& launch, void* stream) {
+    if (launch.tile_count == 0) return PYR_OK;
+    const uint64_t interior = (uint64_t)launch.tile_size * launch.tile_size * launch.film.bins * launch.tile_count;
+    const uint64_t ring = (uint64_t)4 * (launch.tile_size + 1) * launch.film.bins * launch.tile_count;
+    const uint32_t grid_i = (uint32_t)std::min<uint64_t>((interior + BLOCK - 1) / BLOCK, 256 * 32);
+    const uint32_t grid_r = (uint32_t)std::min<uint64_t>((ring + BLOCK - 1) / BLOCK, 256 * 32);
+    hipLaunchKernelGGL(assemble_interior_kernel, dim3(grid_i), dim3(BLOCK), 0, (hipStream_t)stream, launch);
+    hipLaunchKernelGGL(assemble_ring_kernel, dim3(grid_r), dim3(BLOCK), 0, (hipStream_t)stream, launch);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_kernel_error = std::string("assemble kernel launch: ") + hipGetErrorString(err);
         return PYR_ERR_DEVICE;
     }
     return PYR_OK;

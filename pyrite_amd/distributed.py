@@ -1,19 +1,32 @@
-"""Multi-GPU sharding of one render: tiles are independent units (each has its own RNG streams and writes only its own
-pixels, pyrite/src/renderer/simple.rs:41-47), the scene is replicated, so the image's tiles are split into bands of whole tile
-rows dealt to the ranks (see `plan`) with no data-path collective, and the per-rank film windows are brought together by ONE gather.
+"""Multi-GPU sharding of one render, one process per GPU.
 
-Why windows carry a one-row halo: Film::expose recomputes the pixel from the view-plane position (film.rs:233-246) and
-float rounding can put a sample that was drawn on a tile edge into the neighbouring pixel row (probability ~1e-6 per
-sample). A band therefore covers pixel rows [first_tile_row*ts - 1, last_tile_row_end + 1) and rank 0 ADDS the gathered
-windows into the film; overlapping rows (halos, and tile rows shared by two ranks) sum up exactly as they would in a
-single-GPU film. With the per-(tile, iteration) RNG the N-GPU film equals the 1-GPU film up to fp32 add order.
+Tiles are independent units (each has its own RNG streams and exposes only its own pixels, pyrite/src/renderer/simple.rs:41-47)
+and the scene is replicated, so the image's tiles are dealt to the ranks with no data-path collective, every rank renders its
+share in ONE launch into a private film buffer, and ONE gather brings the buffers to rank 0, which adds them into the film.
+This is the host-side twin of include/pyrite_gpu.h's pyr_render_simple_sharded: the same plan, the same buffers, the
+same assembly kernel; `NativeSharded` drives that entry point itself (RCCL send / recv inside the library), `render_sharded`
+does the gather with torch.distributed (RCCL with backend "nccl", gloo on CPU for the tests).
 
-The reference has no counterpart (single process, shared memory); the collective is `torch.distributed.gather`
-(RCCL over xGMI with backend "nccl", gloo on CPU for tests)."""
+Plans (`plan`):
+  "tiles"       rank r of n renders the raster tiles r, r + n, r + 2n, ... into a buffer of ringed tile blocks
+                (PYR_FILM_TILE_BLOCKS: (tile_size + 2)^2 pixels per tile). Every rank sees every part of the image, so the
+                shares cost the same without measuring anything (C3 at 8 ranks: 255 tiles each; a share of contiguous rows
+                costs up to 1.4x the mean there), and the gather moves (34/32)^2 = 1.13x the film.
+  "contiguous"  one band of consecutive tiles per rank and the pixel rows it covers plus one halo row on either side
+                (PYR_FILM_ROWS with a row window). Cheapest to gather; only balanced when cost is uniform over the image.
+The ring / halo is there because Film::expose recomputes the pixel from the view-plane position (film.rs:233-246) and float
+rounding can put a sample drawn on a tile edge into the neighbouring pixel (~1e-6 per sample); rank 0 ADDS the buffers, so
+those samples land where a single-GPU render puts them. With the per-(tile, iteration) RNG the N-GPU film equals the 1-GPU
+film up to fp32 add order."""
 from __future__ import annotations
+
+import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
+
+from . import abi
 
 
 def tile_grid(width, height, tile_size):
@@ -33,7 +46,7 @@ def partition_tiles(num_tiles, world_size):
 
 
 def window_rows(tile_range, tiles_x, tile_size, height):
-    """Pixel rows (first_row, count) a rank's film window must cover: its tile rows plus one halo row on either side."""
+    """Pixel rows (first_row, count) a band's film window must cover: its tile rows plus one halo row on either side."""
     a, b = tile_range
     if b <= a:
         return 0, 0
@@ -43,83 +56,160 @@ def window_rows(tile_range, tiles_x, tile_size, height):
     return lo, hi - lo
 
 
+class Share:
+    """What one rank renders: the tiles tile_begin, tile_begin + tile_stride, ... < tile_end, and the layout of its buffer."""
+
+    def __init__(self, tile_begin, tile_end, tile_stride, layout, rows=(0, 0), tile_size=32):
+        self.tile_begin, self.tile_end, self.tile_stride, self.layout = int(tile_begin), int(tile_end), max(1, int(tile_stride)), int(layout)
+        self.rows, self.tile_size = (int(rows[0]), int(rows[1])), int(tile_size)
+
+    @property
+    def tile_count(self):
+        return max(0, -(-(self.tile_end - self.tile_begin) // self.tile_stride))
+
+    def tiles(self):
+        return range(self.tile_begin, self.tile_end, self.tile_stride)
+
+    def pixels(self, width):
+        """Pixels of the share's buffer (the buffer is float32 [pixels, bins, 2])."""
+        if self.layout == abi.PYR_FILM_TILE_BLOCKS:
+            return self.tile_count * (self.tile_size + 2) ** 2
+        return self.rows[1] * width
+
+    def apply(self, params):
+        """Writes the share into a PyrRenderParams."""
+        params.tile_begin, params.tile_end, params.tile_stride = self.tile_begin, self.tile_end, self.tile_stride
+        params.film_layout = self.layout
+        params.film_row_begin, params.film_row_count = (0, 0) if self.layout == abi.PYR_FILM_TILE_BLOCKS else self.rows
+        return params
+
+    def __repr__(self):
+        return "Share(tiles %d:%d:%d, %s)" % (self.tile_begin, self.tile_end, self.tile_stride,
+                                               "blocks" if self.layout == abi.PYR_FILM_TILE_BLOCKS else "rows %d+%d" % self.rows)
+
+
 def plan(width, height, tile_size, world_size, sharding=None):
-    """For every rank the list of BANDS it renders, identical on all ranks (no communication needed):
-    [[(tile_range, (first_row, rows)), ...], ...]. A band is a contiguous raster tile range plus the pixel rows its film
-    window must cover.
-
-    "contiguous": one band per rank, equal tile counts. Cheapest (one launch, one halo) but only balanced when cost is
-    uniform over the image: on C3 the rows that show the mesh cost 1.6x the others and the slowest of 8 ranks takes 1.37x
-    the mean.  "cyclic": tile rows (cut into pieces when there are few rows per rank) are dealt round-robin, so
-    every rank sees every part of the image; windows grow by the extra halos (34 / 32) and by the row pieces. Default: contiguous for one rank, cyclic otherwise; PYRITE_SHARDING=contiguous|cyclic overrides."""
-    import os
-
+    """The share of every rank, identical on all ranks (no communication needed). Default: the whole image as rows for one
+    rank, "tiles" otherwise; PYRITE_SHARDING=tiles|contiguous overrides."""
     tiles_x, tiles_y = tile_grid(width, height, tile_size)
-    sharding = sharding or os.environ.get("PYRITE_SHARDING") or ("contiguous" if world_size == 1 else "cyclic")
+    total = tiles_x * tiles_y
+    sharding = sharding or os.environ.get("PYRITE_SHARDING") or ("contiguous" if world_size == 1 else "tiles")
     if sharding == "contiguous":
-        ranges = partition_tiles(tiles_x * tiles_y, world_size)
-        return [[(rng, window_rows(rng, tiles_x, tile_size, height))] if rng[1] > rng[0] else [] for rng in ranges]
-    if sharding != "cyclic":
+        return [Share(a, b, 1, abi.PYR_FILM_ROWS, window_rows((a, b), tiles_x, tile_size, height), tile_size) for a, b in partition_tiles(total, world_size)]
+    if sharding != "tiles":
         raise ValueError("unknown sharding %r" % (sharding,))
-    # bands = tile rows, cut into `splits` pieces each when there are fewer than ~8 rows per rank (34 rows on 8 ranks would
-    # leave two ranks with 5 rows against 4); a piece still needs the full-width rows of its tile row as window
-    splits = max(1, min(tiles_x, -(-8 * world_size // tiles_y)))
-    shares = [[] for _ in range(world_size)]
-    k = 0
-    for ty in range(tiles_y):
-        for piece in range(splits):
-            a, b = ty * tiles_x + tiles_x * piece // splits, ty * tiles_x + tiles_x * (piece + 1) // splits
-            if b > a:
-                shares[k % world_size].append(((a, b), window_rows((a, b), tiles_x, tile_size, height)))
-                k += 1
-    return shares
+    return [Share(min(r, total), total, world_size, abi.PYR_FILM_TILE_BLOCKS, tile_size=tile_size) for r in range(world_size)]
 
 
-def window_height(share):
-    """Rows of the stacked film window of one rank: its bands one after the other."""
-    return sum(rows for _, (_, rows) in share)
+def assemble_blocks_torch(film, blocks, share, tile_size):
+    """Adds a share's ringed tile blocks into the whole-image film [height, width, bins, 2] with torch ops (any device): the
+    reference form of pyr_film_blocks_assemble_device, and the one the CPU (gloo) rehearsals use."""
+    height, width = film.shape[0], film.shape[1]
+    tiles_x, _ = tile_grid(width, height, tile_size)
+    side = tile_size + 2
+    blocks = blocks.reshape(-1, side, side, film.shape[2], 2)
+    for k, tile in enumerate(share.tiles()):
+        ty, tx = divmod(tile, tiles_x)
+        x0, y0 = tx * tile_size - 1, ty * tile_size - 1  # image position of the block's corner (the ring)
+        xa, ya, xb, yb = max(x0, 0), max(y0, 0), min(x0 + side, width), min(y0 + side, height)
+        film[ya:yb, xa:xb] += blocks[k, ya - y0:yb - y0, xa - x0:xb - x0]
+    return film
 
 
-def render_sharded(render_window, width, height, bins, tile_size, device, group=None, sharding=None):
-    """Runs `render_window(tile_range, (first_row, rows), window_tensor)` for each band of this rank and gathers the film.
+def assemble(film, buffer, share, tile_size):
+    """Adds one rank's buffer into the film (rank 0's side of the gather)."""
+    if share.tile_count == 0:
+        return film
+    if share.layout == abi.PYR_FILM_TILE_BLOCKS:
+        n = share.pixels(film.shape[1])
+        if film.is_cuda:
+            from ._lib import check, lib
 
-    `window_tensor` is a zeroed float32 [rows, width, bins, 2] view (on `device`) of the rank's stacked window. Returns the
+            desc = abi.PyrFilmDesc(film.shape[1], film.shape[0], film.shape[2], 0.0, 1.0)
+            params = abi.PyrRenderParams()
+            params.tile_size, params.pixel_samples = tile_size, 1
+            share.apply(params)
+            check(lib().pyr_film_blocks_assemble_device(C.byref(desc), C.byref(params), C.c_void_p(buffer.data_ptr()), C.c_void_p(film.data_ptr()),
+                                                        film.device.index or 0, C.c_void_p(torch.cuda.current_stream(film.device).cuda_stream)))
+            return film
+        return assemble_blocks_torch(film, buffer[:n], share, tile_size)
+    first_row, rows = share.rows
+    film[first_row:first_row + rows] += buffer[:rows * film.shape[1]].reshape(rows, film.shape[1], film.shape[2], 2)
+    return film
+
+
+def render_sharded(render_share, width, height, bins, tile_size, device, group=None, sharding=None):
+    """Runs `render_share(share, buffer)` once for this rank's share and gathers the film.
+
+    `buffer` is a zeroed float32 [pixels, bins, 2] tensor on `device` laid out as the share says (Share.layout). Returns the
     full film [height, width, bins, 2] on rank 0 and None elsewhere. Exactly one collective."""
     world_size = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     shares = plan(width, height, tile_size, world_size, sharding)
-    max_rows = max(1, max(window_height(share) for share in shares))
-    window = torch.zeros((max_rows, width, bins, 2), dtype=torch.float32, device=device)
-    offset = 0
-    for tile_range, (first_row, rows) in shares[rank]:
-        render_window(tile_range, (first_row, rows), window[offset:offset + rows])
-        offset += rows
+    mine = shares[rank]
+    if world_size == 1 and mine.layout == abi.PYR_FILM_ROWS and mine.rows == (0, height):
+        film = torch.zeros((height, width, bins, 2), dtype=torch.float32, device=device)
+        render_share(mine, film.view(-1, bins, 2))
+        return film  # the single share is the whole film
+    pixels = max(1, max(s.pixels(width) for s in shares))  # gather wants equal sizes
+    buffer = torch.zeros((pixels, bins, 2), dtype=torch.float32, device=device)
+    if mine.tile_count:
+        render_share(mine, buffer)
     if world_size == 1:
-        share = shares[0]
-        if len(share) == 1 and share[0][1] == (0, height):
-            return window  # the single band is the whole film
-        return _assemble([window], shares, height)
-    if window.is_cuda and dist.get_backend(group) == "gloo":
+        gathered = [buffer]
+    elif buffer.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal on a box without RCCL peers (several ranks on one GPU): gloo gathers host tensors only
-        staged = window.cpu()
+        staged = buffer.cpu()
         gathered = [torch.empty_like(staged) for _ in range(world_size)] if rank == 0 else None
         dist.gather(staged, gathered, dst=0, group=group)
-        if rank != 0:
-            return None
-        return _assemble([g.to(window.device) for g in gathered], shares, height)
-    gathered = [torch.empty_like(window) for _ in range(world_size)] if rank == 0 else None
-    dist.gather(window, gathered, dst=0, group=group)
+        if rank == 0:
+            gathered = [g.to(buffer.device) for g in gathered]
+    else:
+        gathered = [torch.empty_like(buffer) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(buffer, gathered, dst=0, group=group)
     if rank != 0:
         return None
-    return _assemble(gathered, shares, height)
-
-
-def _assemble(windows, shares, height):
-    first = windows[0]
-    film = torch.zeros((height,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
-    for window, share in zip(windows, shares):
-        offset = 0
-        for _, (first_row, rows) in share:
-            film[first_row:first_row + rows] += window[offset:offset + rows]
-            offset += rows
+    film = torch.zeros((height, width, bins, 2), dtype=torch.float32, device=buffer.device)
+    for g, share in zip(gathered, shares):
+        assemble(film, g, share, tile_size)
     return film
+
+
+class NativeSharded:
+    """pyr_comm_* + pyr_render_simple_sharded: the render, the RCCL gather and the assembly all inside libpyrite_gpu.so.
+    The communicator id travels over the torch.distributed group that is already up (any backend)."""
+
+    def __init__(self, device_index, group=None):
+        from ._lib import check, lib
+
+        self._lib, self._check = lib(), check
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device_index = int(device_index)
+        ident = (C.c_uint8 * abi.PYR_COMM_ID_BYTES)()
+        if self.world_size > 1:
+            if self.rank == 0:
+                check(self._lib.pyr_comm_unique_id(ident))
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * abi.PYR_COMM_ID_BYTES).from_buffer_copy(box[0])
+        self.handle = C.c_void_p()
+        check(self._lib.pyr_comm_create(ident, self.rank, self.world_size, self.device_index, C.byref(self.handle)))
+
+    def render(self, renderer, camera, world, film_desc, film_tensor, stream=0):
+        """Adds one sharded render into `film_tensor` (rank 0: float32 [height, width, bins, 2] on this rank's GPU; None elsewhere)."""
+        params = renderer.params()
+        ptr = C.c_void_p(film_tensor.data_ptr()) if film_tensor is not None else None
+        self._check(self._lib.pyr_render_simple_sharded(self.handle, world.scene(self.device_index), C.byref(camera.c), C.byref(film_desc), C.byref(params),
+                                                        ptr, C.c_void_p(stream)))
+
+    def close(self):
+        if self.handle:
+            self._lib.pyr_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

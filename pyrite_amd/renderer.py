@@ -33,12 +33,14 @@ class World:
     def desc(self):
         return self._desc
 
-    def scene(self, device=0):
-        if device not in self._scenes:
+    def scene(self, device=0, slot=0):
+        """The PyrScene on `device` (`slot` > 0: a further copy on the same device, for the one-GPU multi-rank test rig)."""
+        key = device if slot == 0 else (device, slot)
+        if key not in self._scenes:
             handle = C.c_void_p()
             check(lib().pyr_scene_create(C.byref(self._desc), int(device), C.byref(handle)))
-            self._scenes[device] = handle
-        return self._scenes[device]
+            self._scenes[key] = handle
+        return self._scenes[key]
 
     def bvh_info(self, device=0):
         info = abi.PyrBvhInfo()
@@ -97,7 +99,9 @@ class Renderer:
         ts = self.tile_size
         return ((width + ts - 1) // ts) * ((height + ts - 1) // ts)
 
-    def params(self, flags=0, tile_range=None, film_rows=None):
+    def params(self, flags=0, tile_range=None, film_rows=None, share=None):
+        """PyrRenderParams of this renderer. `tile_range` / `film_rows` restrict the call to raster tiles [a, b) and to a window of
+        pixel rows; `share` (pyrite_amd.distributed.Share) sets tiles, stride and film layout at once."""
         p = abi.PyrRenderParams()
         p.bounces, p.pixel_samples, p.light_samples = self.bounces, self.pixel_samples, self.light_samples
         p.spectrum_samples, p.tile_size, p.flags, p.seed = self.spectrum_samples, self.tile_size, flags, self.seed
@@ -105,17 +109,23 @@ class Renderer:
             p.tile_begin, p.tile_end = int(tile_range[0]), int(tile_range[1])
         if film_rows is not None:
             p.film_row_begin, p.film_row_count = int(film_rows[0]), int(film_rows[1])
+        if share is not None:
+            share.apply(p)
         return p
 
     def render(self, film: Film, camera: Camera, world: World, on_status=None, device=0, counters=False, tile_range=None, film_rows=None,
-               window=None):
+               window=None, share=None):
         """Blocking render into a host Film (adds to it). Returns the PyrCounters dict when counters=True.
         `tile_range` restricts the call to raster tiles [a, b); with film_rows=(first_row, rows) the exposures go to `window`,
         a float32 [rows, width, bins, 2] array covering only those rows of the image `film` describes."""
-        params = self.params(abi.PYR_FLAG_COUNTERS if counters else 0, tile_range, film_rows)
+        params = self.params(abi.PYR_FLAG_COUNTERS if counters else 0, tile_range, film_rows, share)
         desc = film.desc()
         if window is not None:
-            assert window.flags["C_CONTIGUOUS"] and window.dtype == np.float32 and window.shape == (film_rows[1], film.width, film.bins, 2)
+            assert window.flags["C_CONTIGUOUS"] and window.dtype == np.float32
+            if share is not None:
+                assert window.size == share.pixels(film.width) * film.bins * 2
+            else:
+                assert window.shape == (film_rows[1], film.width, film.bins, 2)
             check(lib().pyr_render_simple(world.scene(device), C.byref(camera.c), C.byref(desc), C.byref(params), window.ctypes.data,
                                           C.cast(None, abi.PyrProgressFn), None))
             return self.counters(world, device) if counters else None
@@ -134,11 +144,24 @@ class Renderer:
         return None
 
     def render_device(self, film_ptr, film_desc, camera: Camera, world: World, stream=0, device=0, flags=0, tile_range=None,
-                      film_rows=None):
-        """Asynchronous render into DEVICE memory (`film_ptr` = data_ptr of a float32 [rows, w, bins, 2] tensor)."""
-        params = self.params(flags, tile_range, film_rows)
+                      film_rows=None, share=None):
+        """Asynchronous render into DEVICE memory (`film_ptr` = data_ptr of a float32 tensor laid out as the parameters say:
+        [rows, w, bins, 2] pixel rows, or -- with a `share` of tile blocks -- [tiles, ts + 2, ts + 2, bins, 2])."""
+        params = self.params(flags, tile_range, film_rows, share)
         check(lib().pyr_render_simple_device(world.scene(device), C.byref(camera.c), C.byref(film_desc), C.byref(params),
                                              C.c_void_p(film_ptr), C.c_void_p(stream)))
+
+    def render_multi(self, film: Film, camera: Camera, world: World, devices, on_status=None):
+        """pyr_render_simple_multi: one process driving `devices` (a list of device indices; a repeated index is the one-GPU
+        test rig). Blocking; adds into the host Film."""
+        handles = (C.c_void_p * len(devices))(*[world.scene(d, slot=i) for i, d in enumerate(devices)])
+        params = self.params()
+        desc = film.desc()
+        cb = abi.PyrProgressFn(lambda user, percent, message: on_status(int(percent), message.decode())) if on_status else C.cast(None, abi.PyrProgressFn)
+        grains = np.ascontiguousarray(film.grains)
+        check(lib().pyr_render_simple_multi(handles, len(devices), C.byref(camera.c), C.byref(desc), C.byref(params), grains.ctypes.data, cb, None))
+        if grains is not film.grains:
+            film.grains[...] = grains
 
     def counters(self, world: World, device=0):
         out = abi.PyrCounters()

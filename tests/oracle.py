@@ -136,15 +136,18 @@ class OracleScene:
         self.handle = C.c_void_p()
         _check(lib().oracle_scene_create(C.byref(world.desc), C.byref(self.handle)))
 
-    def render(self, renderer, camera, film, threads=1, tile_range=None, film_rows=None, window=None):
+    def render(self, renderer, camera, film, threads=1, tile_range=None, film_rows=None, window=None, share=None):
         """Adds one render into `film.grains`, or -- with film_rows=(first_row, rows) -- into `window`, a float32
-        [rows, width, bins, 2] array covering only those rows of the image `film` describes."""
-        params = renderer.params(0, tile_range, film_rows)
+        [rows, width, bins, 2] array covering only those rows of the image `film` describes, or -- with a
+        pyrite_amd.distributed.Share -- into `window` laid out as the share says (pixel rows or ringed tile blocks)."""
+        params = renderer.params(0, tile_range, film_rows, share)
         desc = film.desc()
         counters = abi.PyrCounters()
         target = film.grains if window is None else window
         assert target.flags["C_CONTIGUOUS"] and target.dtype == np.float32
-        if film_rows is not None:
+        if share is not None:
+            assert window is not None and target.size == share.pixels(film.width) * film.bins * 2
+        elif film_rows is not None:
             assert target.shape == (film_rows[1], film.width, film.bins, 2)
         _check(lib().oracle_render_simple(self.handle, C.byref(camera.c), C.byref(desc), C.byref(params), target.ctypes.data, threads,
                                           C.byref(counters)))

@@ -1,5 +1,5 @@
-"""The N>1 path on CPU: two gloo ranks shard the tiles, render their film windows (with the CPU oracle standing in for
-the HIP kernels -- the sharding, windows and the single gather are what is under test) and rank 0 must end up with the
+"""The N>1 path on CPU: gloo ranks shard the tiles, render their film buffers (with the CPU oracle standing in for the HIP
+kernels -- the plan, the buffers, the single gather and the assembly are what is under test) and rank 0 must end up with the
 film a single process renders."""
 import os
 import socket
@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from pyrite_amd import abi
 from pyrite_amd import distributed as pdist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,24 +23,55 @@ def test_partition_and_windows():
     assert pdist.partition_tiles(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert pdist.partition_tiles(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
     # 1920x1080, 32-pixel tiles: 60 x 34 tiles; contiguous: rank 1 of 8 starts mid-row 4 and ends mid-row 8
-    ((rng, (lo, rows)),) = pdist.plan(1920, 1080, 32, 8, "contiguous")[1]
-    assert rng == (255, 510) and lo == 4 * 32 - 1 and lo + rows == 9 * 32 + 1
-    ((rng, (lo, rows)),) = pdist.plan(1920, 1080, 32, 8, "contiguous")[7]
-    assert lo + rows == 1080  # clamped at the image edge
-    assert pdist.plan(64, 64, 32, 1) == [[((0, 4), (0, 64))]]
+    s = pdist.plan(1920, 1080, 32, 8, "contiguous")[1]
+    assert (s.tile_begin, s.tile_end, s.tile_stride, s.layout) == (255, 510, 1, abi.PYR_FILM_ROWS)
+    assert s.rows[0] == 4 * 32 - 1 and sum(s.rows) == 9 * 32 + 1
+    assert sum(pdist.plan(1920, 1080, 32, 8, "contiguous")[7].rows) == 1080  # clamped at the image edge
+    (s,) = pdist.plan(64, 64, 32, 1)
+    assert (s.tile_begin, s.tile_end, s.rows, s.pixels(64)) == (0, 4, (0, 64), 64 * 64)
     assert pdist.window_rows((2, 2), 2, 32, 64) == (0, 0)
-    assert pdist.plan(64, 32, 32, 4, "contiguous")[3] == []  # two tiles, four ranks: the last two have nothing to do
-    # cyclic (the default for more than one rank): tile rows dealt round-robin, cut in pieces when rows per rank are few
-    shares = pdist.plan(1920, 1080, 32, 2)
-    assert [len(s) for s in shares] == [17, 17] and shares[1][0] == ((60, 120), (31, 34)) and shares[0][0] == ((0, 60), (0, 33))
-    assert shares[1][16] == ((33 * 60, 34 * 60), (33 * 32 - 1, 1080 - 33 * 32 + 1))  # the last, 24-pixel tile row
-    shares = pdist.plan(1920, 1080, 32, 8)  # 34 rows on 8 ranks: half rows, 68 bands
-    assert sorted(len(s) for s in shares) == [8, 8, 8, 8, 9, 9, 9, 9]
-    assert shares[0][0] == ((0, 30), (0, 33)) and shares[1][0] == ((30, 60), (0, 33)) and shares[2][0] == ((60, 90), (31, 34))
+    assert pdist.plan(64, 32, 32, 4, "contiguous")[3].tile_count == 0  # two tiles, four ranks: the last two have nothing to do
+
+
+def test_tile_plan_deals_every_tile_once():
+    # the default for more than one rank: tiles dealt round-robin, one ringed block per tile
     for n in (2, 3, 8):
-        tiles = sorted(rng for share in pdist.plan(1920, 1080, 32, n) for rng, _ in share)
-        assert tiles[0][0] == 0 and tiles[-1][1] == 2040 and all(a[1] == b[0] for a, b in zip(tiles, tiles[1:]))  # every tile once
-    assert pdist.window_height(pdist.plan(1920, 1080, 32, 2)[0]) == 33 + 16 * 34
+        shares = pdist.plan(1920, 1080, 32, n)
+        assert all(s.layout == abi.PYR_FILM_TILE_BLOCKS and s.tile_stride == n for s in shares)
+        tiles = sorted(t for s in shares for t in s.tiles())
+        assert tiles == list(range(2040))
+        assert max(s.tile_count for s in shares) - min(s.tile_count for s in shares) <= 1
+    shares = pdist.plan(1920, 1080, 32, 8)
+    assert [s.tile_count for s in shares] == [255] * 8
+    assert shares[0].pixels(1920) == 255 * 34 * 34
+    # the gather moves (34/32)^2 of the film, not the 2.1x of round 1's half-row bands
+    assert sum(s.pixels(1920) for s in shares) / (1920 * 1080) < 1.14
+    # more ranks than tiles
+    shares = pdist.plan(64, 32, 32, 4)
+    assert [s.tile_count for s in shares] == [1, 1, 0, 0]
+    p = shares[1].apply(abi.PyrRenderParams())
+    assert (p.tile_begin, p.tile_end, p.tile_stride, p.film_layout) == (1, 2, 4, abi.PYR_FILM_TILE_BLOCKS)
+
+
+def test_blocks_assemble_matches_a_direct_scatter():
+    """assemble_blocks_torch against a pixel-by-pixel restatement of the PYR_FILM_TILE_BLOCKS definition (pyrite_gpu.h)."""
+    width, height, ts, bins = 21, 13, 8, 3  # 3 x 2 tiles, both edges cut
+    rng = np.random.default_rng(5)
+    for n, r in ((2, 1), (3, 0), (1, 0)):
+        share = pdist.plan(width, height, ts, n, "tiles")[r]
+        side = ts + 2
+        blocks = rng.random((share.tile_count, side, side, bins, 2)).astype(np.float32)
+        film = pdist.assemble_blocks_torch(torch.zeros((height, width, bins, 2)), torch.from_numpy(blocks).reshape(-1, bins, 2), share, ts).numpy()
+        expect = np.zeros((height, width, bins, 2), dtype=np.float32)
+        tiles_x = (width + ts - 1) // ts
+        for k, tile in enumerate(share.tiles()):
+            ty, tx = divmod(tile, tiles_x)
+            for by in range(side):
+                for bx in range(side):
+                    x, y = tx * ts + bx - 1, ty * ts + by - 1
+                    if 0 <= x < width and 0 <= y < height:
+                        expect[y, x] += blocks[k, by, bx]
+        assert np.array_equal(film, expect)
 
 
 def _free_port():
@@ -62,12 +94,12 @@ def _worker(rank, world_size, port, out_path, sharding):
         r.tile_size = 8  # 5 x 5 tiles (last row 4 pixels high): both ranks end mid-row
         sc = oracle.OracleScene(world)
 
-        def render_window(tile_range, rows, window):
-            view = window.numpy()
-            assert view.flags["C_CONTIGUOUS"] and view.shape[0] == rows[1]
-            sc.render(r, cam, film, threads=1, tile_range=tile_range, film_rows=rows, window=view)
+        def render_share(share, buffer):
+            view = buffer.numpy()
+            assert view.flags["C_CONTIGUOUS"] and view.shape[0] >= share.pixels(film.width)
+            sc.render(r, cam, film, threads=1, share=share, window=view[:share.pixels(film.width)])
 
-        result = pdist.render_sharded(render_window, film.width, film.height, film.bins, r.tile_size, torch.device("cpu"), sharding=sharding)
+        result = pdist.render_sharded(render_share, film.width, film.height, film.bins, r.tile_size, torch.device("cpu"), sharding=sharding)
         if rank == 0:
             np.save(out_path, result.numpy())
         else:
@@ -76,7 +108,7 @@ def _worker(rank, world_size, port, out_path, sharding):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size,sharding", [(2, "cyclic"), (3, "cyclic"), (2, "contiguous"), (3, "contiguous")])
+@pytest.mark.parametrize("world_size,sharding", [(2, "tiles"), (3, "tiles"), (2, "contiguous"), (3, "contiguous")])
 def test_gloo_ranks_reproduce_the_single_process_film(world_size, sharding):
     import oracle
     from pyrite_amd import scenes
@@ -91,3 +123,19 @@ def test_gloo_ranks_reproduce_the_single_process_film(world_size, sharding):
     assert np.array_equal(sharded[..., 1], film.grains[..., 1])  # every exposure arrived exactly once
     assert np.allclose(sharded, film.grains, rtol=1e-6, atol=1e-12)
     assert film.total_weight() == 40 * 36 * 2 * 10
+
+
+def test_ring_catches_the_samples_a_tile_window_would_drop():
+    """A share rendered into ringed blocks holds every exposure of its tiles: the block total equals samples x wavelengths
+    even though a few samples land one pixel outside their tile (tile size 2 makes that common)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from pyrite_amd import scenes
+
+    world, cam, r, film = scenes.build(scenes.c2_cornell(24, 24, 64), seed=3)
+    r.tile_size = 2
+    share = pdist.plan(24, 24, 2, 3)[1]
+    blocks = np.zeros((share.pixels(24), film.bins, 2), dtype=np.float32)
+    c = oracle.OracleScene(world).render(r, cam, film, threads=2, share=share, window=blocks)
+    assert c["samples"] == share.tile_count * 2 * 2 * 64
+    assert blocks[..., 1].sum() == c["samples"] * r.spectrum_samples == c["exposures"]

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import oracle
-from pyrite_amd import scenes
+from pyrite_amd import abi, scenes
 from pyrite_amd.project import renderer
 
 pytestmark = pytest.mark.gpu
@@ -399,8 +399,11 @@ def test_tape_records_the_bound_and_no_more(gpu_lib, monkeypatch):
 def test_full_size_c3_properties(gpu_lib):
     """BASELINE.json's C3 at full size on the stage scheduler with the spectral tape (819,212 triangles, 1920 x 1080, the
     persistent grid at its full width), 2 spp: every sample exposes its wavelengths exactly once; the image rendered in one
-    launch equals the image rendered band by band into row windows the way an 8-rank cyclic plan renders it (pyrite_amd/
-    distributed.py) -- weights exactly, spectra up to the order of the float atomics."""
+    launch equals the image rendered the way an 8-rank plan renders it (pyrite_amd/distributed.py: every rank one launch over
+    its strided tiles into ringed tile blocks, rank 0 adds the blocks with the assembly kernel) -- weights exactly, spectra
+    up to the order of the float atomics."""
+    import torch
+
     from pyrite_amd import distributed as pdist
 
     W, H, spp = 1920, 1080, 2
@@ -411,13 +414,77 @@ def test_full_size_c3_properties(gpu_lib):
     assert c["exposures"] == weight <= W * H * spp * r.spectrum_samples and weight >= 0.9999 * W * H * spp * r.spectrum_samples
     assert not np.isnan(whole.grains).any()
 
-    shares = pdist.plan(W, H, r.tile_size, 8, "cyclic")
-    film = r.new_film(W, H)
-    for share in shares:
-        for tile_range, (first_row, rows) in share:
-            window = np.zeros((rows, W, r.spectrum_bins, 2), dtype=np.float32)
-            r.render(film, cam, world, tile_range=tile_range, film_rows=(first_row, rows), window=window)
-            film.grains[first_row:first_row + rows] += window
-    assert np.array_equal(film.grains[..., 1], whole.grains[..., 1])
-    assert np.allclose(film.grains[..., 0], whole.grains[..., 0], rtol=1e-4, atol=1e-6)
+    dev = torch.device("cuda", 0)
+    desc = whole.desc()
+    film = torch.zeros((H, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    total_samples = 0
+    for share in pdist.plan(W, H, r.tile_size, 8):
+        buffer = torch.zeros((share.pixels(W), r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+        r.render_device(buffer.data_ptr(), desc, cam, world, stream=stream.cuda_stream, device=0, share=share, flags=abi.PYR_FLAG_COUNTERS)
+        total_samples += r.counters(world, 0)["samples"]
+        assert float(buffer[..., 1].sum(dtype=torch.float64)) == r.counters(world, 0)["exposures"]  # the ring holds what spills over a tile's edge
+        pdist.assemble(film, buffer, share, r.tile_size)
+    assert total_samples == W * H * spp
+    film = film.cpu().numpy()
+    assert np.array_equal(film[..., 1], whole.grains[..., 1])
+    assert np.allclose(film[..., 0], whole.grains[..., 0], rtol=1e-4, atol=1e-6)
+    world.close()
+
+
+def test_blocks_assembly_kernel_equals_the_torch_form(gpu_lib):
+    """pyr_film_blocks_assemble_device against pyrite_amd.distributed.assemble_blocks_torch on random blocks: image edges cut
+    tiles in both directions, strides 1 / 2 / 3, rings that overlap blocks of the same set."""
+    import torch
+
+    from pyrite_amd import distributed as pdist
+
+    dev = torch.device("cuda", 0)
+    width, height, ts, bins = 75, 41, 16, 5
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    for n, rank in ((1, 0), (2, 1), (3, 2)):
+        share = pdist.plan(width, height, ts, n, "tiles")[rank]
+        blocks = torch.rand((share.pixels(width), bins, 2), generator=gen)
+        expect = pdist.assemble_blocks_torch(torch.ones((height, width, bins, 2)), blocks, share, ts)
+        got = pdist.assemble(torch.ones((height, width, bins, 2), device=dev), blocks.to(dev), share, ts).cpu()
+        assert torch.allclose(got, expect, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_native_multi_device_render_equals_the_single_device_film(ranks, gpu_lib):
+    """pyr_render_simple_multi with the same GPU standing in for every rank (RCCL refuses two ranks on one device, so the
+    blocks travel by hipMemcpyPeerAsync: the plan, the strided launches, the ringed blocks and the assembly are the same
+    code the RCCL path runs) against one plain render and against the oracle."""
+    world, cam, r, whole = scenes.build(scenes.c2_cornell(72, 56, 6), seed=5)
+    r.tile_size = 16  # 5 x 4 tiles, both edges cut
+    r.render(whole, cam, world)
+    multi = r.new_film(72, 56)
+    seen = []
+    r.render_multi(multi, cam, world, devices=[0] * ranks, on_status=lambda percent, message: seen.append(percent))
+    assert seen == [0, 100]
+    assert np.array_equal(multi.grains[..., 1], whole.grains[..., 1])
+    assert np.allclose(multi.grains, whole.grains, rtol=1e-5)
+    cpu = r.new_film(72, 56)
+    oracle.OracleScene(world).render(r, cam, cpu, threads=4)
+    assert_parity(multi, cpu)
+    world.close()
+
+
+def test_native_sharded_entry_with_one_rank(gpu_lib):
+    """pyr_comm_create / pyr_render_simple_sharded for a world of one: the communicator, the block buffer and the assembly
+    without a peer (the RCCL calls themselves need a second GPU and run in bench.py --gpus N)."""
+    import torch
+
+    from pyrite_amd import distributed as pdist
+
+    world, cam, r, whole = scenes.build(scenes.c2_cornell(64, 48, 4), seed=6)
+    r.render(whole, cam, world)
+    dev = torch.device("cuda", 0)
+    film = torch.zeros((48, 64, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+    comm = pdist.NativeSharded(0)
+    comm.render(r, cam, world, whole.desc(), film, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    comm.close()
+    assert np.array_equal(film.cpu().numpy()[..., 1], whole.grains[..., 1])
+    assert np.allclose(film.cpu().numpy(), whole.grains, rtol=1e-5)
     world.close()

@@ -23,23 +23,21 @@ world_.scene(0)
 dev = torch.device("cuda", 0)
 desc = abi.PyrFilmDesc(W, H, r.spectrum_bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
 stream = torch.cuda.current_stream(dev)
-for sharding in ("contiguous", "cyclic"):
+for sharding in ("contiguous", "tiles"):
     shares = pdist.plan(W, H, r.tile_size, world, sharding)
     times = []
     for share in shares:
-        total = 0.0
-        for tile_range, (first_row, rows) in share:
-            window = torch.zeros((rows, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
-            ms = 0.0
-            for _ in range(2):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                r.render_device(window.data_ptr(), desc, cam, world_, stream=stream.cuda_stream, device=0, tile_range=tile_range, film_rows=(first_row, rows))
-                b.record(stream)
-                torch.cuda.synchronize(dev)
-                ms = a.elapsed_time(b)
-            total += ms
-        times.append(total)
+        buffer = torch.zeros((max(1, share.pixels(W)), r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+        ms = 0.0
+        for _ in range(2):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            if share.tile_count:
+                r.render_device(buffer.data_ptr(), desc, cam, world_, stream=stream.cuda_stream, device=0, share=share)
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            ms = a.elapsed_time(b)
+        times.append(ms)
     mean = sum(times) / len(times)
     print("%-10s per-rank ms: %s | max / mean = %.3f (strong-scaling efficiency bound %.3f)"
           % (sharding, " ".join("%.1f" % t for t in times), max(times) / mean, mean / max(times)), flush=True)
