@@ -616,18 +616,22 @@ DEV f3 sample_hemisphere(Rng& rng, f3 direction) { // math.rs:155-164
 // ------------------------------------------------------------------------------------------------ primitives
 // shapes/mod.rs:75-119, same operation order as the reference.
 DEV bool triangle_test(f3 v1, f3 e1, f3 e2, f3 o, f3 d, float& dist, float& u, float& v) {
+    // The reference returns at each failed test; here every lane runs straight through and the verdicts are combined at the
+    // end -- the same operations in the same order on the lanes that pass, garbage that nobody reads on the others. A wave
+    // executes the whole routine for its slowest lane anyway, and each early exit cost a saved exec mask, a branch and the
+    // mask bookkeeping to merge the outcomes (the nested exits also pushed the kernel's scalar registers into spills).
     f3 p = cross(d, e2);
     float det = dot(e1, p);
-    if (det > -DIST_EPSILON && det < DIST_EPSILON) return false;
+    const bool det_ok = !(det > -DIST_EPSILON && det < DIST_EPSILON);
     float inv_det = 1.0f / det;
     f3 t = o - v1;
     u = dot(t, p) * inv_det;
-    if (u < 0.0f || u > 1.0f) return false;
+    const bool u_ok = !(u < 0.0f || u > 1.0f);
     f3 q = cross(t, e1);
     v = dot(d, q) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) return false;
+    const bool v_ok = !(v < 0.0f || u + v > 1.0f);
     dist = dot(e2, q) * inv_det;
-    return dist > DIST_EPSILON;
+    return det_ok & u_ok & v_ok & (dist > DIST_EPSILON);
 }
 // shapes/mod.rs:57-74 via collision::Sphere (oracle.cpp sphere_intersect).
 DEV bool sphere_test(f3 center, float radius, f3 o, f3 d, float& dist, f3& point) {
@@ -1182,12 +1186,28 @@ struct SceneView {
     const float4* prims;
     bool wide = false; // nodes are Node128 (four children); only the resumable traversal walks those
 };
+// A uniform pointer as a scalar value of its own. The kernel arguments arrive by s_load_dwordx8 / x16 and the register
+// allocator treats each such load's result as one tuple: when scalar registers run short (they do: ~100 uniform launch and
+// scene fields are live across the stage loop) it spills and restores the tuple whole, and the traversal step -- which only
+// wants the node and primitive pointers -- was restoring sixteen registers with sixteen v_readlane per step. The move below
+// is opaque to the compiler, so its result is a two-register value that stays put or spills alone.
+template <typename T>
+DEV const T* own_scalar(const T* p) {
+    unsigned long long in = (unsigned long long)p, out;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(out) : "s"(in));
+    return reinterpret_cast<const T*>(out);
+}
+
 template <bool LDS_SCENE>
 DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_before, bool resumable = false) {
     SceneView v{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
     if (!LDS_SCENE && resumable && S.wide_nodes != nullptr) {
         v.nodes = reinterpret_cast<const float4*>(S.wide_nodes);
         v.wide = true;
+    }
+    if constexpr (!LDS_SCENE) {
+        v.nodes = own_scalar(v.nodes);
+        v.prims = own_scalar(v.prims);
     }
     if constexpr (LDS_SCENE) {
         float4* staged = reinterpret_cast<float4*>(lds + lds_floats_before);
@@ -1759,9 +1779,25 @@ DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, cons
     t.node = c[0];
     return false;
 }
-template <bool COUNT>
+// GLOBAL says the scene pointers are known to point into device memory (everything but a scene staged in LDS): the loads
+// are then global_load, not flat_load (own_scalar's result is an integer to the compiler, so the address space is stated here).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const f4v global_f4v;
+template <bool GLOBAL>
+struct ScenePtr {
+    const float4* p;
+    DEV float4 operator[](size_t i) const {
+        if constexpr (GLOBAL) {
+            const f4v v = ((global_f4v*)p)[i];
+            return make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            return p[i];
+        }
+    }
+};
+template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    const float4* nd = view.nodes + 8 * (size_t)t.node;
+    const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node}; // the wide tree is never staged in LDS
     return wide_node_visit<COUNT>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
 }
 
@@ -1770,7 +1806,7 @@ DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counte
 template <bool COUNT>
 DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_t first, uint32_t count, Trav& t, TravStack& stack, Counters& cnt) {
     const uint32_t shape = __float_as_uint(a.w);
-    float dist, u = 0.0f, v = 0.0f;
+    float dist = 0.0f, u = 0.0f, v = 0.0f;
     bool ok;
     if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
         if (COUNT) cnt.triangle_tests++;
@@ -1780,19 +1816,16 @@ DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_
         if (COUNT) cnt.sphere_tests++;
         ok = sphere_box_guard(mk(a.x, a.y, a.z), b.x, t.o, t.d, t.closest, t.shadow) && sphere_test(mk(a.x, a.y, a.z), b.x, t.o, t.d, dist, point);
     }
-    if (ok) {
-        if (t.shadow) {
-            if (dist > DIST_EPSILON && dist * dist < t.limit) {
-                t.blocked = true;
-                return true;
-            }
-        } else if (dist > DIST_EPSILON && dist < t.closest) {
-            t.closest = dist;
-            t.shape = shape;
-            t.u = u;
-            t.v = v;
-        }
-    }
+    // the verdict as selects (world.rs:290 for an extension ray, tracer.rs:381-389 for a shadow ray), then where to go next
+    ok = ok & (dist > DIST_EPSILON);
+    const bool blocks = ok & t.shadow & (dist * dist < t.limit);
+    const bool closer = ok & !t.shadow & (dist < t.closest);
+    t.blocked = t.blocked | blocks;
+    t.closest = closer ? dist : t.closest;
+    t.shape = closer ? shape : t.shape;
+    t.u = closer ? u : t.u;
+    t.v = closer ? v : t.v;
+    if (blocks) return true;
     if (count > 1) {
         t.node = -1 - (int)(((first + 1) << 3) | (count - 1));
         return false;
@@ -1809,13 +1842,13 @@ DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_
 // does anybody wait. The node arithmetic and the primitive test still run one after the other at partial occupancy, but the
 // round trip -- which is what a step costs (21.9 k cycles per 8-step turn on C3 against ~600 cycles of issue) -- is paid once
 // per step instead of once per kind, and no lane sits a step out as under the node / leaf vote. Wide trees only.
-template <bool COUNT>
+template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_unified(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
     const bool at_node = active && t.node >= 0;
     const uint32_t code = (uint32_t)(-1 - t.node);
     const uint32_t first = code >> 3, count = code & 7u;
     const bool at_prim = active && t.node < 0 && count != 0;
-    const float4* addr = at_node ? view.nodes + 8 * (size_t)t.node : view.prims + 3 * (size_t)first;
+    const ScenePtr<GLOBAL> addr{at_node ? view.nodes + 8 * (size_t)t.node : view.prims + 3 * (size_t)first};
     float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0;
     if (at_node || at_prim) {
         r0 = addr[0];
@@ -1842,11 +1875,11 @@ DEV bool trav_step_unified(const SceneView& view, Trav& t, TravStack& stack, Cou
     return done;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    if (t.node >= 0 && view.wide) return trav_step_wide<COUNT>(view, t, stack, cnt);
+    if (t.node >= 0 && view.wide) return trav_step_wide<COUNT, GLOBAL>(view, t, stack, cnt);
     if (t.node >= 0) {
-        const float4* nd = view.nodes + 4 * t.node;
+        const ScenePtr<GLOBAL> nd{view.nodes + 4 * t.node};
         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
         if (COUNT) cnt.box_tests += 2;
         float e0, e1;
@@ -1875,36 +1908,8 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
     const uint32_t code = (uint32_t)(-1 - t.node);
     const uint32_t first = code >> 3, count = code & 7u;
     if (count != 0) {
-        const float4 a = view.prims[3 * first + 0], b = view.prims[3 * first + 1];
-        const uint32_t shape = __float_as_uint(a.w);
-        float dist, u = 0.0f, v = 0.0f;
-        bool ok;
-        if ((shape >> 30) == PYR_SHAPE_TRIANGLE) {
-            const float4 c = view.prims[3 * first + 2];
-            if (COUNT) cnt.triangle_tests++;
-            ok = triangle_test(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), t.o, t.d, dist, u, v);
-        } else {
-            f3 point;
-            if (COUNT) cnt.sphere_tests++;
-            ok = sphere_box_guard(mk(a.x, a.y, a.z), b.x, t.o, t.d, t.closest, t.shadow) && sphere_test(mk(a.x, a.y, a.z), b.x, t.o, t.d, dist, point);
-        }
-        if (ok) {
-            if (t.shadow) {
-                if (dist > DIST_EPSILON && dist * dist < t.limit) {
-                    t.blocked = true;
-                    return true;
-                }
-            } else if (dist > DIST_EPSILON && dist < t.closest) {
-                t.closest = dist;
-                t.shape = shape;
-                t.u = u;
-                t.v = v;
-            }
-        }
-        if (count > 1) {
-            t.node = -1 - (int)(((first + 1) << 3) | (count - 1));
-            return false;
-        }
+        const ScenePtr<GLOBAL> pr{view.prims + 3 * (size_t)first};
+        return leaf_prim_visit<COUNT>(pr[0], pr[1], pr[2], first, count, t, stack, cnt);
     }
     if (t.sp == 0) return true;
     t.sp--;
@@ -1924,16 +1929,16 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
 #ifndef PYR_UNIFIED_FETCH
 #define PYR_UNIFIED_FETCH 0
 #endif
-template <bool COUNT>
+template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
-    if (PYR_UNIFIED_FETCH && view.wide) return trav_step_unified<COUNT>(view, t, stack, cnt, active);
+    if (PYR_UNIFIED_FETCH && view.wide) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
     if (PYR_VOTE_BOTH > 0) {
         const int want_node = __popcll(__ballot(active && t.node >= 0)), want_leaf = __popcll(__ballot(active && t.node < 0));
         const bool run_node = want_node >= want_leaf || want_node >= PYR_VOTE_BOTH;
         const bool run_leaf = want_leaf > want_node || want_leaf >= PYR_VOTE_BOTH;
         if (active && !(t.node >= 0 ? run_node : run_leaf)) active = false;
     }
-    return active && trav_step<COUNT>(view, t, stack, cnt);
+    return active && trav_step<COUNT, GLOBAL>(view, t, stack, cnt);
 }
 
 // Per-path state of the resumable integrator and the code of its phases; shared by the stage-scheduled kernel (state in
@@ -2492,7 +2497,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
 #endif
             for (int step = 0; step < trav_steps; ++step) {
                 PROF_LANES(3, w.stage == ST_TRAV);
-                if (trav_step_voted<COUNT>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+                if (trav_step_voted<COUNT, !LDS_SCENE>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
             }
             PROF_END(3);
         }
