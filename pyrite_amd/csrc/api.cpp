@@ -207,6 +207,7 @@ struct PyrScene {
     // wavefront scheduler: path pool (grown on demand, kept between renders) and the pinned word the round loop polls
     DeviceBuffer wf_stage, wf_groups, wf_companions, wf_words;
     DeviceBuffer tape; // spectral tape of the stage-scheduled kernel (grown on demand, kept between renders)
+    DeviceBuffer tape_overflow; // one word the kernels set when a path outgrew the tape (checked after blocking renders and by pyr_scene_counters)
     uint32_t wf_slots = 0, wf_companion_rows = 0;
     uint32_t* wf_host_flag = nullptr;
     ~PyrScene() {
@@ -633,10 +634,26 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
             if (rc != PYR_OK) return rc;
         }
         L.tape = (unsigned long long*)scene->tape.ptr;
+        if (!scene->tape_overflow.ptr) {
+            int rc = scene->tape_overflow.alloc(sizeof(uint32_t));
+            if (rc != PYR_OK) return rc;
+            HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
+        }
+        L.tape_overflow = (uint32_t*)scene->tape_overflow.ptr;
     }
     int rc = launch_render(scene->dev, L, count, stream, scene->num_cus);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());
     return PYR_OK;
+}
+
+// After a render has been waited for: did a path outgrow the spectral tape (kernels.hip tape_push)? The film is wrong then.
+int check_tape_overflow(PyrScene* scene) {
+    if (!scene->tape_overflow.ptr) return PYR_OK;
+    uint32_t word = 0;
+    HIP_TRY(hipMemcpy(&word, scene->tape_overflow.ptr, sizeof(word), hipMemcpyDeviceToHost));
+    if (word == 0) return PYR_OK;
+    HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
+    return fail(PYR_ERR_DEVICE, "a path appended more records than the spectral tape's bound allows: the film of that render is invalid");
 }
 
 RenderLaunch make_launch(const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* p, const TilePlan& plan) {
@@ -757,6 +774,7 @@ int pyr_render_simple(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
         HIP_TRY(hipDeviceSynchronize());
         if (on_status) on_status(user, (uint8_t)((sidx + 1) * 100 / slices), message);
     }
+    if ((rc = check_tape_overflow(scene)) != PYR_OK) return rc;
     HIP_TRY(hipMemcpy(film_inout, film_dev.ptr, bytes, hipMemcpyDeviceToHost));
     return PYR_OK;
 }
@@ -804,6 +822,8 @@ int pyr_scene_counters(PyrScene* scene, PyrCounters* out) {
     if (!scene->have_counters) return fail(PYR_ERR_INVALID_ARGUMENT, "no render with PYR_FLAG_COUNTERS has run on this scene");
     HIP_TRY(hipSetDevice(scene->device));
     HIP_TRY(hipDeviceSynchronize());
+    int rc = check_tape_overflow(scene);
+    if (rc != PYR_OK) return rc;
     HIP_TRY(hipMemcpy(out, scene->counters.ptr, sizeof(PyrCounters), hipMemcpyDeviceToHost));
     return PYR_OK;
 }

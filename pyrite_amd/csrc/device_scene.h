@@ -130,6 +130,7 @@ struct RenderLaunch {
     // one column per lane of the persistent grid.
     unsigned long long* tape;
     uint32_t tape_lanes, tape_max_ops;
+    uint32_t* tape_overflow; // device word, set when a path wanted to append more than tape_max_ops records
     uint32_t tape_programs_lds; // programs whose prepared form the kernel keeps in LDS for the replay (set by launch_render; 0 = none)
 };
 

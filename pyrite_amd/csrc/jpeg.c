@@ -2,8 +2,13 @@
  *
  * The reference loads textures with the `image` crate (texture.rs:25-36); its own test project uses JPEG files
  * (pyrite/test/textures). This is a plain ITU T.81 baseline decoder: SOF0, 8-bit, Huffman, DQT / DHT / DRI, chroma
- * subsampling by pixel replication, JFIF YCbCr -> RGB, reference-accuracy floating-point IDCT. Progressive files are
- * rejected. Decoded values can differ from another decoder's by a level or two (IDCT rounding, chroma upsampling filter). */
+ * subsampling by pixel replication, JFIF YCbCr -> RGB, reference-accuracy floating-point IDCT. Progressive files and
+ * baseline files whose scan does not interleave all components are rejected. Decoded values can differ from another
+ * decoder's by a level or two (IDCT rounding, chroma upsampling filter).
+ *
+ * Texture files are untrusted input: every segment is parsed inside its declared length and inside the file, table and
+ * component indices are checked, coefficient categories beyond baseline's are refused, allocations are checked and the
+ * image size is capped. tests/test_textures.py runs truncated and bit-flipped files through an AddressSanitizer build. */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -60,7 +65,7 @@ static int decode(const Huff* h) {
     }
     return -1;
 }
-static int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+static int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; } /* 1 <= t <= 11 at every call */
 
 static const int zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -99,6 +104,7 @@ static int fail_with(const char* message, char* error, size_t error_size) {
 /* Decodes `size` bytes of a JPEG file. On success returns 0 and hands back a malloc'ed width * height * 3 RGB buffer
  * (release it with pyr_image_free); on failure returns -1 with a message in `error`. Not re-entrant (static state). */
 int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* out_height, uint8_t** out_rgb, char* error, size_t error_size) {
+    if (!bytes || !out_width || !out_height || !out_rgb) return fail_with("null argument", error, error_size);
     data = (uint8_t*)bytes;
     size = nbytes;
     if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail_with("not a JPEG file", error, error_size);
@@ -106,6 +112,9 @@ int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* ou
     static Huff dc[4], ac[4];
     int width = 0, height = 0, ncomp = 0, comp_q[4] = {0}, comp_dc[4] = {0}, comp_ac[4] = {0}, comp_h[4] = {1, 1, 1, 1}, comp_v[4] = {1, 1, 1, 1}, restart = 0;
     pos = 2;
+    memset(qt, 0, sizeof(qt));
+    memset(dc, 0, sizeof(dc));
+    memset(ac, 0, sizeof(ac));
     for (;;) {
         if (pos + 4 > size || data[pos] != 0xFF) return fail_with("corrupt JPEG marker stream", error, error_size);
         int marker = data[pos + 1];
@@ -113,57 +122,71 @@ int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* ou
             pos++;
             continue;
         }
+        if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD9)) return fail_with("corrupt JPEG marker stream", error, error_size); /* no length: not legal here */
         int len = (data[pos + 2] << 8) | data[pos + 3];
-        uint8_t* p = data + pos + 4;
-        if (pos + 2 + (size_t)len > size) return fail_with("truncated JPEG segment", error, error_size);
+        if (len < 2 || pos + 2 + (size_t)len > size) return fail_with("truncated JPEG segment", error, error_size);
+        const uint8_t* p = data + pos + 4;
+        const uint8_t* end = data + pos + 2 + len; /* one past the segment's last byte */
         if (marker == 0xDB) {
-            uint8_t* end = data + pos + 2 + len;
             while (p < end) {
-                int pq = p[0] >> 4, tq = p[0] & 3;
+                int pq = p[0] >> 4, tq = p[0] & 15;
                 ++p;
+                if (pq > 1 || tq > 3 || (size_t)(end - p) < (pq ? 128u : 64u)) return fail_with("truncated or corrupt JPEG quantisation table", error, error_size);
                 for (int i = 0; i < 64; ++i) {
                     qt[tq][zigzag[i]] = pq ? (uint16_t)((p[0] << 8) | p[1]) : p[0];
                     p += pq ? 2 : 1;
                 }
             }
         } else if (marker == 0xC4) {
-            uint8_t* end = data + pos + 2 + len;
             while (p < end) {
-                int tc = p[0] >> 4, th = p[0] & 3;
+                if ((size_t)(end - p) < 17) return fail_with("truncated JPEG Huffman table", error, error_size);
+                int tc = p[0] >> 4, th = p[0] & 15;
+                if (tc > 1 || th > 3) return fail_with("corrupt Huffman table", error, error_size);
                 Huff* h = tc ? &ac[th] : &dc[th];
                 int n = 0;
                 h->bits[0] = 0;
                 for (int i = 1; i <= 16; ++i) n += (h->bits[i] = p[i]);
-                if (n > 256) return fail_with("corrupt Huffman table", error, error_size);
-                memcpy(h->vals, p + 17, n);
+                if (n > 256 || (size_t)(end - p) < 17u + (size_t)n) return fail_with("corrupt Huffman table", error, error_size);
+                memcpy(h->vals, p + 17, (size_t)n);
                 build(h);
                 p += 17 + n;
             }
         } else if (marker == 0xC0) {
+            if (len < 8) return fail_with("truncated JPEG frame header", error, error_size);
             height = (p[1] << 8) | p[2];
             width = (p[3] << 8) | p[4];
             ncomp = p[5];
             if (p[0] != 8 || (ncomp != 1 && ncomp != 3) || width <= 0 || height <= 0) return fail_with("unsupported JPEG frame", error, error_size);
+            if (len < 8 + 3 * ncomp) return fail_with("truncated JPEG frame header", error, error_size);
+            if ((uint64_t)width * (uint64_t)height > (1ull << 28)) return fail_with("JPEG image too large (more than 2^28 pixels)", error, error_size);
             for (int i = 0; i < ncomp; ++i) {
                 comp_h[i] = p[7 + 3 * i] >> 4;
                 comp_v[i] = p[7 + 3 * i] & 15;
-                comp_q[i] = p[8 + 3 * i] & 3;
+                comp_q[i] = p[8 + 3 * i];
+                if (comp_q[i] > 3) return fail_with("corrupt JPEG frame header", error, error_size);
                 if (comp_h[i] < 1 || comp_h[i] > 2 || comp_v[i] < 1 || comp_v[i] > 2) return fail_with("unsupported JPEG sampling factors", error, error_size);
             }
         } else if (marker == 0xC2 || marker == 0xC1 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
             return fail_with("only baseline JPEG is supported (this file is progressive / extended / arithmetic coded)", error, error_size);
         } else if (marker == 0xDD) {
+            if (len < 4) return fail_with("truncated JPEG segment", error, error_size);
             restart = (p[0] << 8) | p[1];
         } else if (marker == 0xDA) {
+            if (width == 0) return fail_with("JPEG has no frame header", error, error_size);
+            if (len < 3) return fail_with("truncated JPEG scan header", error, error_size);
             int ns = p[0];
-            for (int i = 0; i < ns && i < 4; ++i) {
-                comp_dc[i] = (p[2 + 2 * i] >> 4) & 3;
-                comp_ac[i] = p[2 + 2 * i] & 3;
+            /* a baseline file may spread its components over several scans; this reader decodes one interleaved scan */
+            if (ns != ncomp) return fail_with("unsupported JPEG: the scan does not interleave all components", error, error_size);
+            if (len < 6 + 2 * ns) return fail_with("truncated JPEG scan header", error, error_size);
+            for (int i = 0; i < ns; ++i) {
+                comp_dc[i] = p[2 + 2 * i] >> 4;
+                comp_ac[i] = p[2 + 2 * i] & 15;
+                if (comp_dc[i] > 3 || comp_ac[i] > 3) return fail_with("corrupt JPEG scan header", error, error_size);
             }
-            pos += 2 + len;
+            pos += 2 + (size_t)len;
             break;
         }
-        pos += 2 + len;
+        pos += 2 + (size_t)len;
     }
     if (width == 0) return fail_with("JPEG has no frame header", error, error_size);
     int hmax = 1, vmax = 1;
@@ -178,6 +201,10 @@ int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* ou
     for (int i = 0; i < ncomp; ++i) {
         plane_w[i] = mcus_x * 8 * comp_h[i];
         planes[i] = (uint8_t*)calloc((size_t)plane_w[i] * mcus_y * 8 * comp_v[i], 1);
+        if (!planes[i]) {
+            for (int j = 0; j < i; ++j) free(planes[j]);
+            return fail_with("out of memory decoding a JPEG", error, error_size);
+        }
     }
     int pred[3] = {0, 0, 0}, count = 0;
     bitcnt = 0;
@@ -195,7 +222,7 @@ int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* ou
                     for (int h = 0; h < comp_h[c]; ++h) {
                         int coef[64] = {0};
                         int t = decode(&dc[comp_dc[c]]);
-                        if (t < 0) goto corrupt;
+                        if (t < 0 || t > 11) goto corrupt; /* baseline DC differences have at most 11 bits */
                         int diff = t ? extend(getbits(t), t) : 0;
                         pred[c] += diff;
                         coef[0] = pred[c];
@@ -210,6 +237,7 @@ int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* ou
                                 }
                                 break;
                             }
+                            if (s > 10) goto corrupt; /* baseline AC coefficients have at most 10 bits */
                             k += r;
                             if (k > 63) break;
                             coef[zigzag[k]] = extend(getbits(s), s);
@@ -221,6 +249,10 @@ int pyr_jpeg_decode(const uint8_t* bytes, size_t nbytes, int* out_width, int* ou
         }
     {
         uint8_t* rgb = (uint8_t*)malloc((size_t)width * height * 3);
+        if (!rgb) {
+            for (int i = 0; i < ncomp; ++i) free(planes[i]);
+            return fail_with("out of memory decoding a JPEG", error, error_size);
+        }
         for (int y = 0; y < height; ++y)
             for (int x = 0; x < width; ++x) {
                 double Y = planes[0][(size_t)(y * comp_v[0] / vmax) * plane_w[0] + x * comp_h[0] / hmax];

@@ -1987,6 +1987,13 @@ struct Walker {
             }
             L.tape[(size_t)n_ops * L.tape_lanes + (blockIdx.x * BLOCK + threadIdx.x)] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
         }
+#ifndef PYR_TAPE_NOSTORE
+        else {
+            // more records than tape_ops_bound() allows for: the bound was derived by hand from trace / trace_direct, so a change
+            // there that outgrows it must not pass as a slightly wrong film -- the host turns this word into PYR_ERR_DEVICE
+            *L.tape_overflow = 1u;
+        }
+#endif
         n_ops++;
     }
     uint32_t chunk = 0; // next chunk of this lane's sample sequence (chunk_begin + wave, + total_waves, ...)
@@ -2287,13 +2294,23 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     uint32_t max_ops = exposing ? (n_ops < L.tape_max_ops ? n_ops : L.tape_max_ops) : 0u;
     for (int off = 32; off > 0; off >>= 1) max_ops = max(max_ops, (uint32_t)__shfl_xor((int)max_ops, off));
     const unsigned long long* my_column = L.tape + (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    constexpr uint32_t ROWS = 8;
+#ifndef PYR_REPLAY_ROWS
+#define PYR_REPLAY_ROWS 8
+#endif
+    constexpr uint32_t ROWS = PYR_REPLAY_ROWS;
     for (uint32_t base = 0; base < items; base += 64) {
         const uint32_t i = base + lane;
         const bool active = i < items;
         const uint32_t rank = active ? i / SS : 0u, k = active ? i - rank * SS : 0u;
         const uint32_t src = wave_list[rank];
         const uint32_t ops = (uint32_t)__shfl((int)n_ops, (int)src);
+#ifdef PYR_REPLAY_PASS_MAX
+        // the rows this pass needs: the longest tape among ITS items (finished lanes are listed in lane order, not by length)
+        uint32_t pass_ops = active ? (ops < L.tape_max_ops ? ops : L.tape_max_ops) : 0u;
+        for (int off = 32; off > 0; off >>= 1) pass_ops = max(pass_ops, (uint32_t)__shfl_xor((int)pass_ops, off));
+#else
+        const uint32_t pass_ops = max_ops;
+#endif
         const uint32_t pixel = (uint32_t)__shfl((int)p.pixel, (int)src);
         const float hero_wl = __shfl(p.wl, (int)src);
         const bool use_additional = __shfl((int)p.use_additional, (int)src) != 0;
@@ -2319,10 +2336,10 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 spectral_values[slot * BLOCK] = eval_prepared<false>(S, q_prog, in);
             }
         }
-        for (uint32_t r0 = 0; r0 < max_ops; r0 += ROWS) {
+        for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
             unsigned long long rows[ROWS];
 #pragma unroll
-            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < max_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
+            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < pass_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
             // all cross-lane reads of the batch first (one wait), then, in the eager form, all value reads (one more)
             uint32_t words[ROWS];
             float factors[ROWS];
@@ -3080,6 +3097,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
         g_kernel_error = "the spectral tape is missing or too small for this launch";
         return PYR_ERR_INVALID_ARGUMENT;
     }
+    if (const char* cut = std::getenv("PYRITE_TEST_TAPE_OPS")) // test switch: pretend the bound were smaller, to see the overflow word work
+        if (uses_tape(scene, launch) && *cut) launch.tape_max_ops = std::min<uint32_t>(launch.tape_max_ops, (uint32_t)std::strtoul(cut, nullptr, 10));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), lds, (hipStream_t)stream, scene, launch);
     err = hipGetLastError();
     if (err != hipSuccess) {

@@ -396,6 +396,24 @@ def test_tape_records_the_bound_and_no_more(gpu_lib, monkeypatch):
         assert_parity(gfilm, cfilm)
 
 
+def test_tape_overflow_is_an_error_not_a_wrong_film(gpu_lib, monkeypatch):
+    """If a path ever wants more records than the tape's bound (a future change to the next-event count, say), the render
+    must fail: the switch below shrinks the tape under the bound to show the overflow word reach the caller."""
+    from pyrite_amd._lib import PyriteGpuError
+
+    monkeypatch.setenv("PYRITE_SCHEDULER", "sm")
+    world, cam, r, film = scenes.build(scenes.c2_cornell(32, 32, 4), seed=1)
+    r.render(film, cam, world)  # the real bound: fine
+    monkeypatch.setenv("PYRITE_TEST_TAPE_OPS", "3")
+    with pytest.raises(PyriteGpuError, match="spectral tape"):
+        r.render(r.new_film(32, 32), cam, world)
+    monkeypatch.delenv("PYRITE_TEST_TAPE_OPS")
+    again = r.new_film(32, 32)
+    r.render(again, cam, world)  # the word was cleared with the error
+    assert np.array_equal(again.grains[..., 1], film.grains[..., 1])
+    world.close()
+
+
 def test_full_size_c3_properties(gpu_lib):
     """BASELINE.json's C3 at full size on the stage scheduler with the spectral tape (819,212 triangles, 1920 x 1080, the
     persistent grid at its full width), 2 spp: every sample exposes its wavelengths exactly once; the image rendered in one

@@ -250,6 +250,65 @@ def _tiny_jpeg(levels, blocks_x):
     return out + data + b"\xff\xd9"
 
 
+def test_jpeg_reader_survives_truncated_and_corrupt_files(tmp_path):
+    """Texture files are untrusted: every truncation of a valid file, a few thousand byte flips and a set of hostile headers go
+    through the reader built with AddressSanitizer + UBSan (CPU build; GPU sanitizers are not available). Nothing may read
+    or write out of bounds, shift by a bad count or leak; a refused file must come with a message."""
+    import os
+    import struct
+    import subprocess
+
+    def segment(marker, body):
+        return b"\xff" + bytes([marker]) + struct.pack(">H", len(body) + 2) + body
+
+    good = _tiny_jpeg([16, 128, 255, 0, 77, 200, 3, 90], 4)
+    cases = [good]
+    cases += [good[:n] for n in range(len(good))]  # every truncation
+    rng = np.random.default_rng(9)
+    for _ in range(4000):  # byte flips, mostly in the headers
+        b = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+        cases.append(bytes(b))
+    soi = b"\xff\xd8"
+    sof = lambda w, h, nc, comps: segment(0xC0, struct.pack(">BHHB", 8, h, w, nc) + comps)  # noqa: E731
+    cases += [
+        soi + segment(0xDB, bytes([0x10]) + bytes(20)),  # 16-bit table that stops early
+        soi + segment(0xC4, bytes([0x00]) + bytes([255] * 16)),  # Huffman counts far beyond the segment
+        soi + segment(0xC4, bytes([0x00]) + bytes([0] * 15 + [200]) + bytes(10)),  # 200 values announced, 10 present
+        soi + sof(65535, 65535, 3, bytes([1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])),  # 12.8 GB image
+        soi + sof(16, 16, 3, bytes([1, 0x22, 0])),  # three components announced, one described
+        soi + sof(16, 16, 1, bytes([1, 0x11, 9])),  # quantisation table 9
+        soi + sof(16, 16, 1, bytes([1, 0x11, 0])) + segment(0xDA, bytes([4, 1, 0, 2, 0, 3, 0, 4, 0])),  # scan with 4 components
+        soi + sof(16, 16, 3, bytes([1, 0x11, 0, 2, 0x11, 0, 3, 0x11, 0])) + segment(0xDA, bytes([1, 1, 0x00, 0, 63, 0])),  # non-interleaved scan
+        soi + sof(16, 16, 1, bytes([1, 0x11, 0])) + segment(0xDA, bytes([1, 1, 0x77, 0, 63, 0])),  # Huffman table 7
+        soi + b"\xff\xdb\x00\x01",  # segment length below 2
+        soi + b"\xff\xd0" * 40,  # restart markers where segments belong
+        soi + segment(0xDD, b""),  # empty restart-interval segment
+    ]
+    # a DC category of 15 (shift counts beyond baseline's 11 bits) with a table that allows it
+    hostile = good.replace(bytes([0, 0, 0, 12] + [0] * 12) + bytes(range(12)), bytes([0, 0, 0, 12] + [0] * 12) + bytes([15] * 12))
+    cases.append(hostile)
+    corpus = tmp_path / "corpus.bin"
+    with open(corpus, "wb") as f:
+        for c in cases:
+            f.write(struct.pack("<I", len(c)) + c)
+    exe = tmp_path / "jpeg_asan"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", str(exe),
+                           os.path.join(root, "pyrite_amd", "csrc", "jpeg.c"), os.path.join(root, "tests", "jpeg_asan_driver.c"), "-lm"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LD_PRELOAD="")
+    run = subprocess.run([str(exe), str(corpus)], capture_output=True, text=True, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    decoded, refused = (int(x) for x in run.stdout.replace(",", "").split() if x.isdigit())
+    assert decoded >= 1 and refused >= len(good) - 40 and decoded + refused == len(cases)
+    for n in (0, 1, 3, 40, len(good) // 2):  # and the Python surface reports them as errors
+        bad = tmp_path / ("cut%d.jpg" % n)
+        bad.write_bytes(good[:n])
+        with pytest.raises(ValueError):
+            images.read_image(str(bad))
+
+
 def test_jpeg_reader_decodes_a_hand_written_baseline_file(tmp_path):
     levels = [16, 128, 255, 0, 77, 200]
     path = tmp_path / "flat.jpg"
