@@ -184,7 +184,7 @@ def test_random_soup_hits_and_film_match_the_oracle(seed, gpu_lib, monkeypatch):
     rays = random_rays(30000, seed, [-5, -5, -5], [5, 5, 5])
     ohits, _ = oracle.OracleScene(world).intersect(rays)
     ghits, _, _ = world.intersect(rays)
-    assert_same_hits(ohits, ghits)
+    assert_same_hits(ohits, ghits, world, rays)
     r = Renderer(pixel_samples=3, bounces=6, light_samples=2, spectrum_samples=5, tile_size=16, seed=seed)
     cam = Camera.from_project(camera.perspective(fov=60, transform=transform.look_at(**{"from": vector(0, -9, 1), "to": vector(0, 0, 0), "up": vector(z=1)})))
     cfilm = r.new_film(40, 30)

@@ -271,7 +271,7 @@ def test_cpp_world_intersect_matches_the_oracle(host, tmp_path):
     got = np.fromfile(hits_path, dtype=np.dtype([("distance", "<f4"), ("shape", "<u4"), ("u", "<f4"), ("v", "<f4")]))
     world, _, _, _ = scenes.build(scenes.c2_cornell(8, 8, 1), seed=1)
     want, _ = oracle.OracleScene(world).intersect(rays)
-    assert_same_hits(want, got)
+    assert_same_hits(want, got, world, rays)
 
 
 @pytest.mark.gpu

@@ -36,7 +36,8 @@ def test_spheres_example_matches_the_reference_image():
     assert yr[0:2].max() < 0.01 and ym[0:2].max() < 0.01  # black above the horizon
     floor = (slice(27, 32), slice(4, 60))
     ratio = ym[floor] / yr[floor]
-    assert 0.8 < np.median(ratio) < 1.1, np.median(ratio)  # measured 0.90
+    # 0.90 -- a difference of colour rendition, not of light transport: see test_gpu_renders_match_the_reference_images
+    assert 0.87 < np.median(ratio) < 0.94, np.median(ratio)
     # the left ball is the red / orange one, the right ball the green one, in both
     for img in (ref, mine):
         left, right = img[8:18, 4:12].mean((0, 1)), img[8:18, 52:60].mean((0, 1))
@@ -109,7 +110,17 @@ def test_gpu_renders_match_the_reference_images(gpu_lib):
         yr, ym = ref @ LUMA, mine @ LUMA
         assert np.corrcoef(yr.ravel(), ym.ravel())[0, 1] > 0.99, name
         if floor is not None:
-            assert 0.8 < np.median(ym[floor] / yr[floor]) < 1.1
+            # The white floor (albedo 1 under the D65 lamp) comes out at 0.90x the image's luminance. tools/spheres_image_study.py
+            # (profiles/r02_spheres_image_study.txt) took that number apart at the project's own 600 spp, where two seeds differ by
+            # 0.3 % per cell: it does not move with bounces (8 / 16 / 32), light samples (4 / 1), spectrum samples (10 / 1) or
+            # bins (64 / the lua's ignored `spectrum_bins = 50`), so it is not light transport; it differs per channel
+            # (R 0.96, G 0.90, B 0.87: the image's floor is neutral, today's development renders a D65-lit white slightly warm,
+            # as the reference's CURRENT code does too -- the textures image, rendered by it, matches per channel within a few
+            # percent) and saturated colours differ most (the red ball's green channel is 0.07x: the image is less saturated).
+            # That is the spectrum -> RGB step of an earlier build. The windows are what the noise floor supports.
+            assert 0.88 < np.median(ym[floor] / yr[floor]) < 0.93
+            per_channel = np.median(mine[floor] / ref[floor], axis=(0, 1))
+            assert np.all(np.abs(per_channel - np.array([0.953, 0.889, 0.868])) < 0.025), per_channel
         else:
             assert 0.85 < ym.mean() / yr.mean() < 1.1
     world, cam, r, film = scenes.build(scenes.textures_reference_example(TEXTURES, 1024, 512, 400), seed=1)
