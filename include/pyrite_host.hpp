@@ -254,7 +254,7 @@ class World { // world.rs:31-36
   public:
     static std::unique_ptr<World> from_project(const WorldProject& world, const std::string& base_dir = ".");
     ~World();
-    PyrScene* scene(int device = 0); // created on first use (BVH build + upload)
+    PyrScene* scene(int device = 0, int copy = 0); // created on first use (BVH build + upload); `copy` > 0: a further scene on the same device
     // World::intersect (world.rs:273-299) for a batch of rays, [n][6] = origin, direction: closest hits, on the GPU
     std::vector<PyrHit> intersect(const std::vector<float>& rays, int device = 0, PyrCounters* counters = nullptr);
     FlatScene& flat() { return flat_; }
@@ -263,7 +263,7 @@ class World { // world.rs:31-36
   private:
     World() = default;
     FlatScene flat_;
-    std::map<int, PyrScene*> scenes_;
+    std::map<std::pair<int, int>, PyrScene*> scenes_;
 };
 
 struct Camera { // cameras.rs:20-27
@@ -300,6 +300,11 @@ class Renderer { // renderer/mod.rs:18-28, Algorithm::Simple
     // The seam: blocking; adds into `film`; `on_status` runs on the calling thread. Returns the kernel counters when asked to.
     void render(Film& film, const Camera& camera, World& world, const std::function<void(Progress)>& on_status = nullptr, int device = 0,
                 PyrCounters* counters = nullptr) const;
+    // The same seam over several GPUs of this process (pyr_render_simple_multi): the scene is replicated on every listed
+    // device, the image's tiles are dealt round-robin, one launch per device, one RCCL gather of the film blocks to
+    // devices[0]. What the reference does with its worker threads (renderer/mod.rs:125-189) a host does with its GPUs.
+    // A device listed twice is the one-GPU test rig (pyrite_gpu.h).
+    void render(Film& film, const Camera& camera, World& world, const std::vector<int>& devices, const std::function<void(Progress)>& on_status = nullptr) const;
 };
 
 // ------------------------------------------------------------------------------------------------ project files

@@ -512,7 +512,7 @@ struct OracleScene {
 
 namespace {
 
-struct Counters {
+struct alignas(128) Counters { // one per worker thread, bumped at every box test: a cache line pair of its own, or 256 threads fight over lines
     uint64_t samples = 0, extension_rays = 0, shadow_rays = 0, box_tests = 0, triangle_tests = 0, sphere_tests = 0,
              plane_tests = 0, shaded_hits = 0, exposures = 0;
     void add_to(PyrCounters* c) const {

@@ -1041,12 +1041,12 @@ std::unique_ptr<World> World::from_project(const WorldProject& world, const std:
 World::~World() {
     for (auto& kv : scenes_) pyr_scene_destroy(kv.second);
 }
-PyrScene* World::scene(int device) {
-    auto it = scenes_.find(device);
+PyrScene* World::scene(int device, int copy) {
+    auto it = scenes_.find({device, copy});
     if (it != scenes_.end()) return it->second;
     PyrScene* handle = nullptr;
     check_status(pyr_scene_create(&flat_.desc(), device, &handle));
-    scenes_[device] = handle;
+    scenes_[{device, copy}] = handle;
     return handle;
 }
 
@@ -1100,6 +1100,20 @@ void Renderer::render(Film& film, const Camera& camera, World& world, const std:
     Trampoline t{&on_status};
     check_status(pyr_render_simple(world.scene(device), &camera.c, &desc, &p, film.grains.data(), on_status ? on_status_trampoline : nullptr, on_status ? &t : nullptr));
     if (counters != nullptr) check_status(pyr_scene_counters(world.scene(device), counters));
+}
+
+void Renderer::render(Film& film, const Camera& camera, World& world, const std::vector<int>& devices, const std::function<void(Progress)>& on_status) const {
+    if (devices.empty()) throw ProjectError("render: no device given");
+    PyrRenderParams p{};
+    p.bounces = bounces, p.pixel_samples = pixel_samples, p.light_samples = light_samples, p.spectrum_samples = spectrum_samples, p.tile_size = tile_size;
+    p.seed = seed;
+    std::vector<PyrScene*> scenes;
+    std::map<int, int> seen;
+    for (int device : devices) scenes.push_back(world.scene(device, seen[device]++));
+    const PyrFilmDesc desc = film.desc();
+    Trampoline t{&on_status};
+    check_status(pyr_render_simple_multi(scenes.data(), (uint32_t)scenes.size(), &camera.c, &desc, &p, film.grains.data(), on_status ? on_status_trampoline : nullptr,
+                                         on_status ? &t : nullptr));
 }
 
 Film::Film(uint32_t width_, uint32_t height_, uint32_t grains_per_pixel, float wavelength_start_, float wavelength_end)

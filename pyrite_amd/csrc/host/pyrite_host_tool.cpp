@@ -285,10 +285,20 @@ int main(int argc, char** argv) {
             Film film = r.new_film(project.image.width, project.image.height);
             std::printf("The scene contains %zu objects.\n", world->num_objects()); // world.rs:251-254
             int last = -1;
-            r.render(film, cam, *world, [&](Progress p) {
+            auto report = [&](Progress p) {
                 if (p.progress != last) std::printf("%s... %3d %%\n", p.message, (int)p.progress);
                 last = p.progress;
-            });
+            };
+            if (const char* list = std::getenv("PYRITE_DEVICES")) { // e.g. 0,1,2,3 -- Renderer::render over several GPUs
+                std::vector<int> devices;
+                for (const char* c = list; *c;) {
+                    devices.push_back((int)std::strtol(c, const_cast<char**>(&c), 10));
+                    if (*c == ',') ++c;
+                }
+                r.render(film, cam, *world, devices, report);
+            } else {
+                r.render(film, cam, *world, report);
+            }
             std::ofstream f(argv[8], std::ios::binary);
             f.write(reinterpret_cast<const char*>(film.grains.data()), (std::streamsize)(film.grains.size() * sizeof(PyrGrain)));
             std::printf("film weight %.0f\n", film.total_weight());
