@@ -1875,36 +1875,38 @@ DEV bool trav_step_unified(const SceneView& view, Trav& t, TravStack& stack, Cou
     return done;
 }
 
+// An inner-node visit of a lane whose t.node >= 0. Returns true when the traversal has finished.
 template <bool COUNT, bool GLOBAL = true>
-DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    if (t.node >= 0 && view.wide) return trav_step_wide<COUNT, GLOBAL>(view, t, stack, cnt);
-    if (t.node >= 0) {
-        const ScenePtr<GLOBAL> nd{view.nodes + 4 * t.node};
-        const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-        if (COUNT) cnt.box_tests += 2;
-        float e0, e1;
-        slab_pair(n0, n1, n2, t.o, t.inv, e0, e1);
-        const bool h0 = (e0 >= 0.0f) & (e0 < t.closest), h1 = (e1 >= 0.0f) & (e1 < t.closest);
-        const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-        if (h0 && h1) {
-            const bool swap = e1 < e0;
-            t.node = swap ? c1 : c0;
-            stack.push(t.sp, swap ? c0 : c1);
-            t.sp++;
-        } else if (h0) {
-            t.node = c0;
-        } else if (h1) {
-            t.node = c1;
-        } else {
-            if (t.sp == 0) return true;
-            t.sp--;
-            t.node = stack.pop(t.sp);
-        }
-        return false;
+DEV bool trav_node_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
+    if (view.wide) return trav_step_wide<COUNT, GLOBAL>(view, t, stack, cnt);
+    const ScenePtr<GLOBAL> nd{view.nodes + 4 * t.node};
+    const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+    if (COUNT) cnt.box_tests += 2;
+    float e0, e1;
+    slab_pair(n0, n1, n2, t.o, t.inv, e0, e1);
+    const bool h0 = (e0 >= 0.0f) & (e0 < t.closest), h1 = (e1 >= 0.0f) & (e1 < t.closest);
+    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    if (h0 && h1) {
+        const bool swap = e1 < e0;
+        t.node = swap ? c1 : c0;
+        stack.push(t.sp, swap ? c0 : c1);
+        t.sp++;
+    } else if (h0) {
+        t.node = c0;
+    } else if (h1) {
+        t.node = c1;
+    } else {
+        if (t.sp == 0) return true;
+        t.sp--;
+        t.node = stack.pop(t.sp);
     }
-    // A leaf is walked one primitive per step (the code in t.node shrinks: first + 1, count - 1), in leaf order. Looping over
-    // the whole leaf here made every wave pay for its fullest leaf (4 primitives) at each step while most lanes were at
-    // inner nodes: 17 % VALU lane occupancy in the traversal kernel (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU).
+    return false;
+}
+// One primitive of the leaf a lane stands in (t.node < 0). A leaf is walked one primitive per step (the code in t.node shrinks:
+// first + 1, count - 1), in leaf order. Looping over the whole leaf here made every wave pay for its fullest leaf (4
+// primitives) at each step while most lanes were at inner nodes: 17 % VALU lane occupancy in the traversal kernel.
+template <bool COUNT, bool GLOBAL = true>
+DEV bool trav_leaf_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
     const uint32_t code = (uint32_t)(-1 - t.node);
     const uint32_t first = code >> 3, count = code & 7u;
     if (count != 0) {
@@ -1915,6 +1917,10 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
     t.sp--;
     t.node = stack.pop(t.sp);
     return false;
+}
+template <bool COUNT, bool GLOBAL = true>
+DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
+    return t.node >= 0 ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : trav_leaf_step<COUNT, GLOBAL>(view, t, stack, cnt);
 }
 
 // One step for the lanes of a wave that have a ray in flight (`active`), with a vote: a step is an inner-node visit or a
@@ -1932,11 +1938,18 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
 template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
     if (PYR_UNIFIED_FETCH && view.wide) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
+    const bool at_node = t.node >= 0;
+    const unsigned long long nodes = __ballot(active && at_node), leaves = __ballot(active && !at_node);
+    if (PYR_VOTE_BOTH > 64) {
+        // majority only: the choice is wave-uniform, so it is a scalar branch to ONE of the two bodies, not two masked regions
+        if (__popcll(nodes) >= __popcll(leaves)) return (active && at_node) ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
+        return (active && !at_node) ? trav_leaf_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
+    }
     if (PYR_VOTE_BOTH > 0) {
-        const int want_node = __popcll(__ballot(active && t.node >= 0)), want_leaf = __popcll(__ballot(active && t.node < 0));
+        const int want_node = __popcll(nodes), want_leaf = __popcll(leaves);
         const bool run_node = want_node >= want_leaf || want_node >= PYR_VOTE_BOTH;
         const bool run_leaf = want_leaf > want_node || want_leaf >= PYR_VOTE_BOTH;
-        if (active && !(t.node >= 0 ? run_node : run_leaf)) active = false;
+        if (active && !(at_node ? run_node : run_leaf)) active = false;
     }
     return active && trav_step<COUNT, GLOBAL>(view, t, stack, cnt);
 }

@@ -38,7 +38,7 @@ for spec in args:
         print("%-40s TIMEOUT" % spec, flush=True)
         sys.exit(1)  # a hung kernel: start nothing else
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    if out.returncode != 0 or not lines:
+    if not lines:
         print("%-40s FAILED rc=%d %s" % (spec, out.returncode, (out.stderr or out.stdout)[-400:].replace("\n", " | ")), flush=True)
         continue
     j = json.loads(lines[-1])
