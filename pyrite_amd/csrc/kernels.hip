@@ -2297,9 +2297,15 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 #ifdef PYR_TAPE_NOREPLAY
     if (n_ops < 1000000u) return;
 #endif
-    if (exposing) wave_list[__popcll(mask & ((1ull << lane) - 1ull))] = lane;
+    // The finished lanes are listed with the paths that keep their companions first, the dispersed ones behind them: a
+    // dispersed path exposes its hero wavelength only (simple.rs:133-139), so it is ONE item, not S of which S - 1 idle --
+    // on C5 a third of the paths disperse and a turn's items drop from 10 n to ~7 n, often a whole pass of 64 less.
+    const unsigned long long full_mask = __ballot(exposing && p.use_additional);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t n_full = (uint32_t)__popcll(full_mask);
+    if (exposing) wave_list[p.use_additional ? __popcll(full_mask & below) : n_full + __popcll(mask & ~full_mask & below)] = lane;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t SS = L.spectrum_samples, items = n * SS;
+    const uint32_t SS = L.spectrum_samples, full_items = n_full * SS, items = full_items + (n - n_full);
     // Longest tape among the finished lanes. The wave reads the tape row by row: a row (one record index of all 64 lanes) is 512
     // contiguous bytes, so every lane loads its own column's record -- one coalesced load per row, eight rows in flight -- and
     // an item takes the record of the lane it replays with a cross-lane read. (Reading record after record of one column from
@@ -2314,7 +2320,8 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     for (uint32_t base = 0; base < items; base += 64) {
         const uint32_t i = base + lane;
         const bool active = i < items;
-        const uint32_t rank = active ? i / SS : 0u, k = active ? i - rank * SS : 0u;
+        const bool full = i < full_items; // an item of a path that kept its companions; else the hero of a dispersed path
+        const uint32_t rank = !active ? 0u : (full ? i / SS : n_full + (i - full_items)), k = !active ? 0u : (full ? i - rank * SS : SS - 1u);
         const uint32_t src = wave_list[rank];
         const uint32_t ops = (uint32_t)__shfl((int)n_ops, (int)src);
 #ifdef PYR_REPLAY_PASS_MAX
@@ -2326,9 +2333,8 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 #endif
         const uint32_t pixel = (uint32_t)__shfl((int)p.pixel, (int)src);
         const float hero_wl = __shfl(p.wl, (int)src);
-        const bool use_additional = __shfl((int)p.use_additional, (int)src) != 0;
         const bool hero = k == SS - 1;
-        const bool run = active && (hero || use_additional);
+        const bool run = active;
         const float wl = hero ? hero_wl : wave_wl[k * BLOCK + src];
         float refl = 1.0f, bright = 0.0f, value = 0.0f;
         uint32_t value_of = 0xFFFFFFFFu;
