@@ -564,7 +564,7 @@ int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
 // slots = 1.3 GB at 10 spectrum samples. Kept on the scene between renders, regrown when a render needs more.
 int wavefront_pool(PyrScene* scene, const RenderLaunch& L, WfPool& pool) {
     const char* e = std::getenv("PYRITE_WF_SLOTS");
-    uint64_t max_slots = e && *e ? std::strtoull(e, nullptr, 10) : (4ull << 20);
+    uint64_t max_slots = e && *e ? std::strtoull(e, nullptr, 10) : (16ull << 20);
     max_slots = std::max<uint64_t>(64, max_slots & ~63ull);
     const uint64_t chunks = L.chunk_end - L.chunk_begin;
     const uint32_t slots = (uint32_t)std::min<uint64_t>(chunks * 64ull, max_slots);
@@ -596,6 +596,25 @@ int wavefront_pool(PyrScene* scene, const RenderLaunch& L, WfPool& pool) {
     return PYR_OK;
 }
 
+// The spectral tape ([tape_max_ops][tape_lanes] 8-byte records) and the overflow word, kept on the scene between renders.
+int reserve_tape(PyrScene* scene, RenderLaunch& L, hipStream_t stream) {
+    const size_t bytes = (size_t)L.tape_lanes * L.tape_max_ops * sizeof(unsigned long long);
+    if (bytes > scene->tape.bytes) {
+        HIP_TRY(hipStreamSynchronize(stream)); // an earlier render of this scene may still be reading the old tape
+        scene->tape.release();
+        int rc = scene->tape.alloc(bytes);
+        if (rc != PYR_OK) return rc;
+    }
+    L.tape = (unsigned long long*)scene->tape.ptr;
+    if (!scene->tape_overflow.ptr) {
+        int rc = scene->tape_overflow.alloc(sizeof(uint32_t));
+        if (rc != PYR_OK) return rc;
+        HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
+    }
+    L.tape_overflow = (uint32_t*)scene->tape_overflow.ptr;
+    return PYR_OK;
+}
+
 int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stream) {
     if (L.chunk_end == L.chunk_begin) return PYR_OK;
     const char* e = std::getenv("PYRITE_SCHEDULER");
@@ -613,6 +632,11 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         WfPool pool{};
         int rc = wavefront_pool(scene, L, pool);
         if (rc != PYR_OK) return rc;
+        if (wavefront_uses_tape(scene->dev, L)) { // one tape column per pool slot
+            L.tape_lanes = pool.n;
+            L.tape_max_ops = tape_ops_bound(L);
+            if ((rc = reserve_tape(scene, L, stream)) != PYR_OK) return rc;
+        }
         rc = launch_wavefront(scene->dev, L, count, stream, scene->num_cus, pool, scene->wf_host_flag);
         if (rc != PYR_OK) return fail(rc, kernels_last_error());
         return PYR_OK;
@@ -626,20 +650,8 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     if (L.scheduler == 1 && scene->dev.needs_interpreter == 0) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
         L.tape_max_ops = tape_ops_bound(L);
-        const size_t bytes = (size_t)L.tape_lanes * L.tape_max_ops * sizeof(unsigned long long);
-        if (bytes > scene->tape.bytes) {
-            HIP_TRY(hipStreamSynchronize(stream)); // an earlier render of this scene may still be reading the old tape
-            scene->tape.release();
-            int rc = scene->tape.alloc(bytes);
-            if (rc != PYR_OK) return rc;
-        }
-        L.tape = (unsigned long long*)scene->tape.ptr;
-        if (!scene->tape_overflow.ptr) {
-            int rc = scene->tape_overflow.alloc(sizeof(uint32_t));
-            if (rc != PYR_OK) return rc;
-            HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
-        }
-        L.tape_overflow = (uint32_t*)scene->tape_overflow.ptr;
+        int rc = reserve_tape(scene, L, stream);
+        if (rc != PYR_OK) return rc;
     }
     int rc = launch_render(scene->dev, L, count, stream, scene->num_cus);
     if (rc != PYR_OK) return fail(rc, kernels_last_error());

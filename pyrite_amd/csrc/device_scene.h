@@ -194,6 +194,7 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
 // (the loop's end is decided by the device). `host_flag` is one pinned host word.
 int launch_wavefront(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus, const WfPool& pool,
                      volatile uint32_t* host_flag);
+bool wavefront_uses_tape(const DevScene& scene, const RenderLaunch& launch); // the wavefront logic kernel records a tape for this launch
 const char* kernels_last_error();
 bool scene_is_lds_resident(const DevScene& scene);
 

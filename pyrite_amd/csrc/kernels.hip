@@ -1978,6 +1978,7 @@ template <bool COUNT, bool INTERP, bool TAPE = false>
 struct Walker {
     uint32_t stage = ST_NEW;
     uint32_t n_ops = 0; // TAPE: records on this path's tape
+    uint32_t tape_column = 0; // TAPE: this path's column of the tape (the lane of the persistent grid, or the pool slot)
     const uint32_t* tape_prepared = nullptr; // TAPE, eager replay: the kernel's LDS table of prepared programs, else nullptr
     DEV void tape_push(const RenderLaunch& L, uint32_t kind, uint32_t program, float s, bool hero_only = false) {
 #ifndef PYR_TAPE_NOSTORE
@@ -1998,7 +1999,7 @@ struct Walker {
                     word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | e[7];
                 }
             }
-            L.tape[(size_t)n_ops * L.tape_lanes + (blockIdx.x * BLOCK + threadIdx.x)] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
+            L.tape[(size_t)n_ops * L.tape_lanes + tape_column] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
         }
 #ifndef PYR_TAPE_NOSTORE
         else {
@@ -2288,8 +2289,8 @@ struct Walker {
 // (algorithm.rs:78). Consecutive records of one program (the light samples of one estimation) share one look-up, as in the
 // synchronous walk. Must be called by every lane of the wave.
 template <bool COUNT>
-DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, const Path& p, const float* wave_wl, uint32_t* wave_list,
-                      const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
+DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wave_wl,
+                      uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = __ballot(exposing);
     const uint32_t n = (uint32_t)__popcll(mask);
@@ -2312,7 +2313,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     // the item's lane was a chain of dependent HBM round trips: it took a quarter of the render.)
     uint32_t max_ops = exposing ? (n_ops < L.tape_max_ops ? n_ops : L.tape_max_ops) : 0u;
     for (int off = 32; off > 0; off >>= 1) max_ops = max(max_ops, (uint32_t)__shfl_xor((int)max_ops, off));
-    const unsigned long long* my_column = L.tape + (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const unsigned long long* my_column = L.tape + tape_column;
 #ifndef PYR_REPLAY_ROWS
 #define PYR_REPLAY_ROWS 8
 #endif
@@ -2442,6 +2443,27 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     __builtin_amdgcn_wave_barrier();
 }
 
+// The replay's LDS table of prepared programs (8 words each: mode, constant / scale, the spectrum record, and the slot of the
+// program's value among the programs that read a spectrum), followed by the slot -> program list. Returns the number of
+// spectrum-reading programs when they fit the kTapeEagerSlots value rows (the replay then looks each up once per item), else
+// 0 (looked up record by record). Called by every thread of the workgroup; ends with a barrier.
+DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const RenderLaunch& L, uint32_t* prepared_lds) {
+    auto reads_spectrum = [&](uint32_t i) { return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && S0.programs[i].fast != FAST_NONE; };
+    uint32_t n_spectral = 0;
+    for (uint32_t i = 0; i < L.tape_programs_lds; ++i) n_spectral += reads_spectrum(i) ? 1u : 0u;
+    for (uint32_t i = threadIdx.x; i < L.tape_programs_lds; i += BLOCK) {
+        const Prepared q = prepare_program<false>(S, i);
+        uint32_t slot = 0;
+        for (uint32_t j = 0; j < i; ++j) slot += reads_spectrum(j) ? 1u : 0u;
+        uint32_t* e = prepared_lds + 8 * i;
+        e[0] = q.mode, e[1] = __float_as_uint(q.c), e[2] = q.sp.format, e[3] = __float_as_uint(q.sp.min), e[4] = __float_as_uint(q.sp.max);
+        e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = slot;
+        if (reads_spectrum(i) && slot < kTapeEagerSlots) prepared_lds[8 * L.tape_programs_lds + slot] = i;
+    }
+    __syncthreads();
+    return n_spectral > kTapeEagerSlots ? 0u : n_spectral; // too many for the reserved rows: the replay looks them up record by record
+}
+
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
@@ -2474,20 +2496,9 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
     uint32_t n_spectral = 0;
     float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
     if constexpr (TAPE) {
-        auto reads_spectrum = [&](uint32_t i) { return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && S0.programs[i].fast != FAST_NONE; };
-        for (uint32_t i = 0; i < L.tape_programs_lds; ++i) n_spectral += reads_spectrum(i) ? 1u : 0u;
-        for (uint32_t i = threadIdx.x; i < L.tape_programs_lds; i += BLOCK) {
-            const Prepared q = prepare_program<false>(S, i);
-            uint32_t slot = 0;
-            for (uint32_t j = 0; j < i; ++j) slot += reads_spectrum(j) ? 1u : 0u;
-            uint32_t* e = prepared_lds + 8 * i;
-            e[0] = q.mode, e[1] = __float_as_uint(q.c), e[2] = q.sp.format, e[3] = __float_as_uint(q.sp.min), e[4] = __float_as_uint(q.sp.max);
-            e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = slot;
-            if (reads_spectrum(i) && slot < kTapeEagerSlots) prepared_lds[8 * L.tape_programs_lds + slot] = i;
-        }
-        __syncthreads();
-        if (n_spectral > kTapeEagerSlots) n_spectral = 0; // too many for the reserved rows: the replay looks them up record by record
+        n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
         if (n_spectral != 0) w.tape_prepared = prepared_lds;
+        w.tape_column = blockIdx.x * BLOCK + threadIdx.x;
     }
 
     PROF_DECL;
@@ -2502,7 +2513,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
 
         if (nE >= expose_lanes || nE == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
-            if constexpr (TAPE) replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+            if constexpr (TAPE) replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
             w.expose_and_restart(S, L, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
@@ -2800,6 +2811,166 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderL
     }
     if (had_work) wf_store(P, slot, planes, w, spec, n_comp);
     if (__ballot(w.stage == ST_TRAV) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u;
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ---- the wavefront logic kernel with the spectral tape (scenes without interpreter programs: every BASELINE config) ----------
+// Same split as above, but `contribute` does not run in the visits: they append to the slot's column of the tape (Walker
+// TAPE) and the visit in which a path ends replays it, wave-wide, exactly as the stage-scheduled kernel does. The state a
+// visit moves shrinks accordingly -- no brightness / reflectance, the S - 1 companion wavelengths are written when a sample
+// starts and read again only when it is exposed:
+//   0 chunk | bounce:12 n_ops:12 events:2 flags:6 | nee_lamp:16 nee_i:16 | pixel        4 ray origin, limit     5 ray direction
+//   1 rng                                                                              6 closest, shape, u, v
+//   2 wl (hero), ls_scale, ls_color, ls_material                                        7 b_position   8 b_normal   9 b_out
+// nee_probability is a function of the launch alone and b_nff is +-b_normal (one flag bit). A visit that comes back from an
+// extension ray reads 0 1 2 4 5 6, one that comes back from a shadow ray 0 1 2 7 8 9; both write 0 1 (2) 4 5, and 7 8 9 when
+// a next-event estimation starts: ~190 B per visit against ~345 B before, and a third of the phase code.
+constexpr uint32_t WFT_FLAG_ADDITIONAL = 1u << 26, WFT_FLAG_SAMPLE_LIGHT = 1u << 27, WFT_FLAG_HAS_BRDF = 1u << 28, WFT_FLAG_LS_PENDING = 1u << 29,
+                   WFT_FLAG_LS_PHYSICAL = 1u << 30, WFT_FLAG_NFF_FLIPPED = 1u << 31;
+
+template <bool COUNT>
+DEV void wft_load(const DevScene& S, const RenderLaunch& L, const WfPool& P, uint32_t slot, uint32_t word, Walker<COUNT, false, true>& w) {
+    w.stage = word & WF_STAGE_MASK;
+    w.t.blocked = (word & WF_BLOCKED) != 0;
+    w.t.shadow = (word & WF_SHADOW) != 0;
+    const float4* g = reinterpret_cast<const float4*>(P.groups) + slot;
+    const size_t n = P.n;
+    const float4 g0 = g[0 * n];
+    w.chunk = __float_as_uint(g0.x);
+    if (w.stage == ST_NEW) return;
+    const float4 g2 = g[2 * n];
+    const uint32_t packed = __float_as_uint(g0.y), nee = __float_as_uint(g0.z);
+    w.p.pixel = __float_as_uint(g0.w);
+    w.p.wl = g2.x;
+    w.n_ops = (packed >> 12) & 0xfffu;
+    w.p.use_additional = (packed & WFT_FLAG_ADDITIONAL) != 0;
+    if (w.stage == ST_EXPOSE) return; // a path that ended in the last visit: the replay needs its tape, pixel, wavelengths and this flag
+    const float4 g1 = g[1 * n];
+    w.p.bounce = packed & 0xfffu;
+    w.p.events = (packed >> 24) & 3u;
+    w.p.sample_light = (packed & WFT_FLAG_SAMPLE_LIGHT) != 0;
+    w.b_has_brdf = (packed & WFT_FLAG_HAS_BRDF) != 0;
+    w.ls_pending = (packed & WFT_FLAG_LS_PENDING) != 0;
+    w.ls_physical = (packed & WFT_FLAG_LS_PHYSICAL) != 0;
+    w.nee_lamp = nee & 0xffffu;
+    w.nee_i = nee >> 16;
+    w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
+    w.ls_scale = g2.y, w.ls_color = __float_as_uint(g2.z), w.ls_material = __float_as_uint(g2.w);
+    // shade()'s own expression (tracer.rs:365): the same operations on the same launch constants give the same bits
+    w.nee_probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * (1.0f / (float)S.num_lamps));
+    if (w.stage == ST_NEE) {
+        const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n];
+        w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9);
+        w.b_nff = (packed & WFT_FLAG_NFF_FLIPPED) ? -w.b_normal : w.b_normal;
+        w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event); its direction is not read again
+    } else {
+        const float4 g4 = g[4 * n], g5 = g[5 * n], g6 = g[6 * n];
+        w.t.o = xyz(g4), w.t.limit = g4.w, w.t.d = xyz(g5);
+        w.t.closest = g6.x, w.t.shape = __float_as_uint(g6.y), w.t.u = g6.z, w.t.v = g6.w;
+    }
+    w.p.o = w.t.o, w.p.d = w.t.d;
+}
+
+template <bool COUNT>
+DEV void wft_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUNT, false, true>& w, Spectral& spec, uint32_t n_comp) {
+    float4* g = reinterpret_cast<float4*>(P.groups) + slot;
+    const size_t n = P.n;
+    // b_nff is b_normal or its negation (shade: dot(ray_d, normal) < 0 ? normal : -normal): the sign of any non-zero component tells
+    const bool flipped = (w.b_nff.x != w.b_normal.x) | (w.b_nff.y != w.b_normal.y) | (w.b_nff.z != w.b_normal.z);
+    const uint32_t packed = (w.p.bounce & 0xfffu) | ((w.n_ops & 0xfffu) << 12) | ((w.p.events & 3u) << 24) | (w.p.use_additional ? WFT_FLAG_ADDITIONAL : 0u) |
+                            (w.p.sample_light ? WFT_FLAG_SAMPLE_LIGHT : 0u) | (w.b_has_brdf ? WFT_FLAG_HAS_BRDF : 0u) | (w.ls_pending ? WFT_FLAG_LS_PENDING : 0u) |
+                            (w.ls_physical ? WFT_FLAG_LS_PHYSICAL : 0u) | (flipped ? WFT_FLAG_NFF_FLIPPED : 0u);
+    g[0 * n] = make_float4(__uint_as_float(w.chunk), __uint_as_float(packed), __uint_as_float((w.nee_lamp & 0xffffu) | (w.nee_i << 16)), __uint_as_float(w.p.pixel));
+    P.stage[slot] = w.stage | (w.t.shadow ? WF_SHADOW : 0u);
+    if (w.stage == ST_DONE || w.stage == ST_EXPOSE) return; // EXPOSE: parked for the next visit, which replays its tape (group 2 holds its wavelength since the sample started)
+    g[1 * n] = make_float4(__uint_as_float(w.p.rng.x), __uint_as_float(w.p.rng.y), __uint_as_float(w.p.rng.z), __uint_as_float(w.p.rng.w));
+    if (w.touched & (TOUCH_NEW | TOUCH_LIGHT)) g[2 * n] = make_float4(w.p.wl, w.ls_scale, __uint_as_float(w.ls_color), __uint_as_float(w.ls_material));
+    g[4 * n] = mk4(w.t.o, w.t.limit);
+    g[5 * n] = mk4(w.t.d, 0.0f);
+    if (planes) g[6 * n] = make_float4(w.t.closest, __uint_as_float(w.t.shape), w.t.u, w.t.v);
+    if ((w.touched & TOUCH_SHADE) && w.ls_pending) { // a next-event estimation started in this visit: its context outlives the visit
+        g[7 * n] = mk4(w.b_position, 0.0f);
+        g[8 * n] = mk4(w.b_normal, 0.0f);
+        g[9 * n] = mk4(w.b_out, 0.0f);
+    }
+    if (w.touched & TOUCH_NEW) {
+        float* c = P.companions + slot;
+        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)k * n] = spec.wl(k);
+    }
+}
+
+template <bool COUNT, bool LDS_TABLES>
+__global__ __launch_bounds__(BLOCK, 4) void wf_logic_tape_kernel(DevScene S0, RenderLaunch L, WfPool P) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    Spectral spec{lds + threadIdx.x, SS};
+    Counters cnt{};
+    const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots; // S wavelengths, the per-wave lane lists, the eager value rows (replay_tapes)
+    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, spectral_rows * BLOCK);
+    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + spectral_rows * BLOCK + (LDS_TABLES ? S0.lds_table_floats : 0));
+    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
+    const float* wave_wl = lds + (threadIdx.x & ~63u);
+    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
+    float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < kFeedSegments) P.next[threadIdx.x * kFeedCursorStride] = 0; // the traversal kernel that follows starts afresh
+    // threads take the workgroup's slots sorted by entry stage (see wf_logic_kernel)
+    __shared__ uint32_t wave_counts[BLOCK / 64][4];
+    __shared__ uint16_t sorted_slot[BLOCK];
+    const uint32_t first_slot = blockIdx.x * BLOCK;
+    uint32_t my_word = ST_DONE;
+    if (first_slot + threadIdx.x < P.n) my_word = P.stage[first_slot + threadIdx.x];
+    const uint32_t my_stage = my_word & WF_STAGE_MASK;
+    const uint32_t key = my_stage == ST_SHADE ? 0u : (my_stage == ST_NEE ? 1u : (my_stage == ST_DONE ? 3u : 2u));
+    const uint32_t lane_id = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
+    uint32_t rank_in_wave = 0;
+    for (uint32_t k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(key == k);
+        if (key == k) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane_id) - 1ull));
+        if (lane_id == 0) wave_counts[wave_id][k] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t position = rank_in_wave;
+    for (uint32_t k = 0; k < 4; ++k)
+        for (uint32_t v = 0; v < BLOCK / 64; ++v)
+            if (k < key || (k == key && v < wave_id)) position += wave_counts[v][k];
+    sorted_slot[position] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    const uint32_t slot = first_slot + sorted_slot[threadIdx.x];
+    const bool live = slot < P.n;
+    const uint32_t n_comp = SS - 1;
+    const uint32_t total_waves = P.n / 64u;
+    Walker<COUNT, false, true> w;
+    w.stage = ST_DONE;
+    w.tape_column = slot;
+    w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
+    const bool planes = S.num_planes != 0;
+    if (live) {
+        const uint32_t word = P.stage[slot];
+        if ((word & WF_STAGE_MASK) != ST_DONE) wft_load(S, L, P, slot, word, w);
+    }
+    const bool had_work = w.stage != ST_DONE;
+    // A path that ends in this visit is PARKED in EXPOSE and replayed by the next visit: the threads of a workgroup take their
+    // slots sorted by entry stage, so the parked paths of 256 slots then sit side by side and the replay (and the start of the
+    // next sample behind it) runs at the width of a wave -- done on the spot it ran for the three or four lanes of a wave that
+    // happen to finish in a round, every round (3.3 ms per round of 16 Mi slots against the traversal kernel's 1.9).
+    const bool ending = w.stage == ST_EXPOSE || w.stage == ST_NEW; // entered the visit at the end of a path (or before its first)
+    if (w.stage == ST_EXPOSE) { // the companions were put down in HBM when the sample started
+        const float* c = P.companions + slot;
+        for (uint32_t k = 0; k < n_comp; ++k) spec.wl(k) = c[(size_t)k * P.n];
+    }
+    if (__ballot(ending) != 0) {
+        replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+        if (ending) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
+    }
+    for (;;) {
+        const bool any_shade = __ballot(w.stage == ST_SHADE) != 0;
+        const bool any_nee = __ballot(w.stage == ST_NEE) != 0;
+        if (!(any_shade || any_nee)) break; // every lane holds a ray to trace, is parked at its path's end, or is done
+        if (any_shade) w.shade(S, L, spec, cnt);
+        if (__ballot(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
+    }
+    if (had_work) wft_store(P, slot, planes, w, spec, n_comp);
+    if (__ballot(w.stage == ST_TRAV || w.stage == ST_EXPOSE) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u; // parked paths need another round too
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -3160,6 +3331,10 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
     return PYR_OK;
 }
 
+bool wavefront_uses_tape(const DevScene& scene, const RenderLaunch& launch) {
+    return scene.needs_interpreter == 0 && launch.bounces < 4096u && tape_ops_bound(launch) < 4096u && scene.num_lamps < 65536u && launch.light_samples < 65536u;
+}
+
 int launch_wavefront(const DevScene& scene, const RenderLaunch& launch_in, bool with_counters, void* stream_, int num_cus, const WfPool& pool,
                      volatile uint32_t* host_flag) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -3174,9 +3349,22 @@ int launch_wavefront(const DevScene& scene, const RenderLaunch& launch_in, bool 
     using LogicKernel = void (*)(DevScene, RenderLaunch, WfPool);
     static const LogicKernel logic_variants[2][2] = {{wf_logic_kernel<false, false>, wf_logic_kernel<false, true>},
                                                      {wf_logic_kernel<true, false>, wf_logic_kernel<true, true>}};
-    LogicKernel logic = logic_variants[with_counters ? 1 : 0][interp ? 1 : 0];
+    static const LogicKernel tape_variants[2][2] = {{wf_logic_tape_kernel<false, false>, wf_logic_tape_kernel<false, true>},
+                                                    {wf_logic_tape_kernel<true, false>, wf_logic_tape_kernel<true, true>}};
+    // the tape form packs bounce / record counts into 12 bits each and the lamp / light-sample numbers into 16
+    const bool tape = wavefront_uses_tape(scene, launch);
+    LogicKernel logic = tape ? tape_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0] : logic_variants[with_counters ? 1 : 0][interp ? 1 : 0];
     auto trav = with_counters ? wf_trav_kernel<true> : wf_trav_kernel<false>;
-    const size_t lds_logic = (size_t)3 * launch.spectrum_samples * BLOCK * sizeof(float) + (size_t)scene.lds_table_floats * sizeof(float);
+    size_t lds_logic = (size_t)3 * launch.spectrum_samples * BLOCK * sizeof(float) + (size_t)scene.lds_table_floats * sizeof(float);
+    if (tape) {
+        launch.tape_programs_lds = tape_programs_in_lds(scene);
+        if (launch.tape == nullptr || launch.tape_lanes < pool.n || launch.tape_max_ops < tape_ops_bound(launch) || launch.tape_overflow == nullptr) {
+            g_kernel_error = "the spectral tape is missing or too small for this wavefront launch";
+            return PYR_ERR_INVALID_ARGUMENT;
+        }
+        lds_logic = ((size_t)launch.spectrum_samples + 1 + kTapeEagerSlots) * BLOCK * sizeof(float) + (size_t)scene.lds_table_floats * sizeof(float) +
+                    ((size_t)launch.tape_programs_lds * 8 + kTapeEagerSlots) * sizeof(uint32_t);
+    }
     const size_t lds_trav = (size_t)launch.stack_lds * BLOCK * sizeof(int);
     if (lds_logic > 160 * 1024) {
         g_kernel_error = "spectrum_samples need more than 160 KB of LDS per workgroup";
@@ -3198,7 +3386,7 @@ int launch_wavefront(const DevScene& scene, const RenderLaunch& launch_in, bool 
     constexpr int kBatch = 8;
     // every round advances every live path by one ray, and a sample traces at most bounces + 2 * light_samples rays
     const uint64_t chunks = launch.chunk_end - launch.chunk_begin, waves = pool.n / 64u;
-    const uint64_t max_rounds = ((chunks + waves - 1) / waves) * ((uint64_t)launch.bounces + 2ull * launch.light_samples + 2ull) + kBatch;
+    const uint64_t max_rounds = ((chunks + waves - 1) / waves) * ((uint64_t)launch.bounces + 2ull * launch.light_samples + 3ull) + kBatch; // + the round a finished path waits parked (tape form)
     for (uint64_t round = 0;; round += kBatch) {
         if (round > max_rounds) {
             g_kernel_error = "wavefront render did not finish within its round bound";
