@@ -199,7 +199,7 @@ struct PyrScene {
     int num_cus = 0;
     DevScene dev{};
     PyrBvhInfo info{};
-    DeviceBuffer wide_nodes, nodes, prims, tri_shade, spheres, sphere_material, planes, plane_material, lamps, materials, components, programs, instrs, spectra,
+    DeviceBuffer wide_nodes, wide_pair_nodes, pair_prims, nodes, prims, tri_shade, spheres, sphere_material, planes, plane_material, lamps, materials, components, programs, instrs, spectra,
         spectrum_data, rgb_basis, counters, tri_tex, sphere_tex_scale, plane_frames, textures, texture_data;
     PyrCounters last_counters{};
     bool have_counters = false;
@@ -435,6 +435,38 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         wide = collapse_to_wide(bvh);
         if (wide.stack_need > kMaxStackDepth) wide = WideBvh{};
     }
+    // Triangle pairs for the wide tree's leaves (device_scene.h DevPrimPair): every leaf gets ceil(n / 2) records of its own and
+    // its code in the wide nodes is rewritten to count in records. PYRITE_PAIR_PRIMS=0 keeps the one-primitive records (A/B).
+    std::vector<DevPrimPair> pairs;
+    std::vector<Node128> pair_nodes;
+    const char* pair_env = std::getenv("PYRITE_PAIR_PRIMS");
+    if (!wide.nodes.empty() && d->num_spheres == 0 && !(pair_env && pair_env[0] == '0')) {
+        pair_nodes = wide.nodes;
+        for (Node128& node : pair_nodes)
+            for (int k = 0; k < 4; ++k) {
+                const int32_t code = node.child[k];
+                if (code >= 0 || code == kEmptyChild) continue;
+                const uint32_t first = (uint32_t)(-1 - code) >> 3, count = (uint32_t)(-1 - code) & 7u;
+                node.child[k] = encode_leaf((uint32_t)pairs.size(), count);
+                for (uint32_t j = 0; j < count; j += 2) {
+                    DevPrimPair pr;
+                    std::memset(&pr, 0, sizeof(pr));
+                    for (uint32_t h = 0; h < 2; ++h) {
+                        if (j + h >= count) {
+                            pr.q[1][2 + h] = shape_bits(PYR_HIT_NONE);
+                            continue;
+                        }
+                        const DevPrim& t = prims[first + j + h];
+                        pr.q[0][0 + h] = t.a[0], pr.q[0][2 + h] = t.a[1], pr.q[1][0 + h] = t.a[2], pr.q[1][2 + h] = t.a[3];
+                        pr.q[2][0 + h] = t.b[0], pr.q[2][2 + h] = t.b[1], pr.q[3][0 + h] = t.b[2];
+                        pr.q[3][2 + h] = t.c[0], pr.q[4][0 + h] = t.c[1], pr.q[4][2 + h] = t.c[2];
+                    }
+                    pairs.push_back(pr);
+                }
+            }
+    }
+    if ((rc = s->pair_prims.upload(pairs.data(), pairs.size() * sizeof(DevPrimPair)))) return rc;
+    if ((rc = s->wide_pair_nodes.upload(pair_nodes.data(), pair_nodes.size() * sizeof(Node128)))) return rc;
     if ((rc = s->wide_nodes.upload(wide.nodes.data(), wide.nodes.size() * sizeof(Node128)))) return rc;
     if ((rc = s->prims.upload(prims.data(), prims.size() * sizeof(DevPrim)))) return rc;
     if ((rc = s->tri_shade.upload(shade.data(), shade.size() * sizeof(DevTriShade)))) return rc;
@@ -456,6 +488,8 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.nodes = (const float*)s->nodes.ptr;
     v.wide_nodes = wide.nodes.empty() ? nullptr : (const float*)s->wide_nodes.ptr;
     v.wide_stack_depth = std::max(1u, wide.stack_need);
+    v.pair_prims = pairs.empty() ? nullptr : (const float*)s->pair_prims.ptr;
+    v.wide_pair_nodes = pairs.empty() ? nullptr : (const float*)s->wide_pair_nodes.ptr;
     v.prims = (const float*)s->prims.ptr;
     v.tri_shade = (const float*)s->tri_shade.ptr;
     v.spheres = (const float*)s->spheres.ptr;

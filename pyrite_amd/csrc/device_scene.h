@@ -14,6 +14,16 @@ struct DevPrim {
     float a[4], b[4], c[4];
 };
 
+// Two triangles of one leaf of the WIDE tree, component by component, 80 bytes = five float4:
+//   (v1.x[2], v1.y[2]) (v1.z[2], shape[2]) (e1.x[2], e1.y[2]) (e1.z[2], e2.x[2]) (e2.y[2], e2.z[2])
+// so that a (triangle A, triangle B) pair of every component sits in an aligned register pair and both Moeller-Trumbore
+// tests run in packed-f32 instructions. A leaf of n triangles owns ceil(n / 2) consecutive records; the odd one out is paired
+// with an all-zero triangle (det = 0: never hit) whose shape is PYR_HIT_NONE. Only built when every primitive in the tree is
+// a triangle; the wide tree's leaf codes then count in these records: -1 - (first_pair << 3 | triangles left).
+struct DevPrimPair {
+    float q[5][4];
+};
+
 // Shading record of a triangle, indexed by ORIGINAL triangle index, 48 bytes:
 //   (n1.xyz, material), (n2.xyz, 0), (n3.xyz, 0).
 struct DevTriShade {
@@ -67,6 +77,8 @@ struct DevScene {
     const float* nodes;  // Node64[], 16 floats each
     const float* wide_nodes; // Node128[], 32 floats each, or nullptr: the tree the resumable traversal walks on big scenes
     uint32_t wide_stack_depth; // stack entries that tree can need
+    const float* pair_prims;      // DevPrimPair[], or nullptr
+    const float* wide_pair_nodes; // the wide tree once more with leaf codes that count in DevPrimPair records (the stage-scheduled render walks this copy; the ray-batch kernels keep the one-primitive records: they are bound by bytes through L1, and a pair is 80 B where a lone triangle is 48)
     const float* prims;  // DevPrim[], 12 floats each
     const float* tri_shade; // DevTriShade[]
     const float* spheres;   // [n][4] centre, radius (original order)

@@ -1185,7 +1185,9 @@ struct SceneView {
     const float4* nodes;
     const float4* prims;
     bool wide = false; // nodes are Node128 (four children); only the resumable traversal walks those
+    const float4* pairs = nullptr; // wide tree only: its leaves index triangle pairs (DevPrimPair), not `prims`
 };
+DEV SceneView wide_or_binary_view(const DevScene& S); // the view the traversal kernels walk (defined below own_scalar)
 // A uniform pointer as a scalar value of its own. The kernel arguments arrive by s_load_dwordx8 / x16 and the register
 // allocator treats each such load's result as one tuple: when scalar registers run short (they do: ~100 uniform launch and
 // scene fields are live across the stage loop) it spills and restores the tuple whole, and the traversal step -- which only
@@ -1198,6 +1200,15 @@ DEV const T* own_scalar(const T* p) {
     return reinterpret_cast<const T*>(out);
 }
 
+DEV SceneView wide_or_binary_view(const DevScene& S) {
+    SceneView v{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), false, nullptr};
+    if (S.wide_nodes != nullptr) {
+        v.nodes = reinterpret_cast<const float4*>(S.wide_nodes);
+        v.wide = true;
+    }
+    return v;
+}
+
 template <bool LDS_SCENE>
 DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_before, bool resumable = false) {
     SceneView v{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims)};
@@ -1205,9 +1216,14 @@ DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_bef
         v.nodes = reinterpret_cast<const float4*>(S.wide_nodes);
         v.wide = true;
     }
+    if (!LDS_SCENE && resumable && S.wide_nodes != nullptr && S.pair_prims != nullptr) {
+        v.nodes = reinterpret_cast<const float4*>(S.wide_pair_nodes);
+        v.pairs = reinterpret_cast<const float4*>(S.pair_prims);
+    }
     if constexpr (!LDS_SCENE) {
         v.nodes = own_scalar(v.nodes);
         v.prims = own_scalar(v.prims);
+        v.pairs = own_scalar(v.pairs);
     }
     if constexpr (LDS_SCENE) {
         float4* staged = reinterpret_cast<float4*>(lds + lds_floats_before);
@@ -1905,10 +1921,63 @@ DEV bool trav_node_step(const SceneView& view, Trav& t, TravStack& stack, Counte
 // One primitive of the leaf a lane stands in (t.node < 0). A leaf is walked one primitive per step (the code in t.node shrinks:
 // first + 1, count - 1), in leaf order. Looping over the whole leaf here made every wave pay for its fullest leaf (4
 // primitives) at each step while most lanes were at inner nodes: 17 % VALU lane occupancy in the traversal kernel.
+// Two triangles of a leaf in one step, both Moeller-Trumbore tests in packed f32 (DevPrimPair): the operations of
+// triangle_test, component pairs side by side, and the verdicts applied in leaf order -- triangle A, then triangle B against
+// the closest distance A left -- so the outcome is the one two single steps give. A ray makes 3.3 primitive steps on C3
+// against 4.5 node visits; with pairs it makes ~1.9, the wave's vote goes to the node kind more often and finds more lanes
+// there, and a pair costs ~1.3 single tests.
+template <bool COUNT>
+DEV bool leaf_pair_visit(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4, uint32_t first, uint32_t count, Trav& t,
+                         TravStack& stack, Counters& cnt) {
+    const f2v v1x = {q0.x, q0.y}, v1y = {q0.z, q0.w}, v1z = {q1.x, q1.y};
+    const f2v e1x = {q2.x, q2.y}, e1y = {q2.z, q2.w}, e1z = {q3.x, q3.y};
+    const f2v e2x = {q3.z, q3.w}, e2y = {q4.x, q4.y}, e2z = {q4.z, q4.w};
+    const uint32_t shape_a = __float_as_uint(q1.z), shape_b = __float_as_uint(q1.w);
+    if (COUNT) cnt.triangle_tests += count >= 2u ? 2u : 1u;
+    const f2v dx = {t.d.x, t.d.x}, dy = {t.d.y, t.d.y}, dz = {t.d.z, t.d.z};
+    const f2v ox = {t.o.x, t.o.x}, oy = {t.o.y, t.o.y}, oz = {t.o.z, t.o.z};
+    // triangle_test, shapes/mod.rs:75-119, for both triangles: p = d x e2, det = e1 . p, t = o - v1, u = (t . p) / det,
+    // q = t x e1, v = (d . q) / det, dist = (e2 . q) / det -- the same operations in the same order per component
+    const f2v px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;
+    const f2v det = e1x * px + e1y * py + e1z * pz;
+    const f2v inv_det = {1.0f / det.x, 1.0f / det.y};
+    const f2v tx = ox - v1x, ty = oy - v1y, tz = oz - v1z;
+    const f2v u = (tx * px + ty * py + tz * pz) * inv_det;
+    const f2v qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    const f2v v = (dx * qx + dy * qy + dz * qz) * inv_det;
+    const f2v dist = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+    auto passes = [](float det_, float u_, float v_, float dist_) {
+        return !(det_ > -DIST_EPSILON && det_ < DIST_EPSILON) & !(u_ < 0.0f || u_ > 1.0f) & !(v_ < 0.0f || u_ + v_ > 1.0f) & (dist_ > DIST_EPSILON);
+    };
+    const bool ok_a = passes(det.x, u.x, v.x, dist.x), ok_b = passes(det.y, u.y, v.y, dist.y) & (count >= 2u);
+    const bool blocks = t.shadow & ((ok_a & (dist.x * dist.x < t.limit)) | (ok_b & (dist.y * dist.y < t.limit)));
+    const bool closer_a = ok_a & !t.shadow & (dist.x < t.closest);
+    const float after_a = closer_a ? dist.x : t.closest;
+    const bool closer_b = ok_b & !t.shadow & (dist.y < after_a);
+    t.blocked = t.blocked | blocks;
+    t.closest = closer_b ? dist.y : after_a;
+    t.shape = closer_b ? shape_b : (closer_a ? shape_a : t.shape);
+    t.u = closer_b ? u.y : (closer_a ? u.x : t.u);
+    t.v = closer_b ? v.y : (closer_a ? v.x : t.v);
+    if (blocks) return true;
+    if (count > 2u) {
+        t.node = -1 - (int)(((first + 1u) << 3) | (count - 2u));
+        return false;
+    }
+    if (t.sp == 0) return true;
+    t.sp--;
+    t.node = stack.pop(t.sp);
+    return false;
+}
+
 template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_leaf_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
     const uint32_t code = (uint32_t)(-1 - t.node);
     const uint32_t first = code >> 3, count = code & 7u;
+    if (count != 0 && view.wide && view.pairs != nullptr) {
+        const ScenePtr<true> pr{view.pairs + 5 * (size_t)first};
+        return leaf_pair_visit<COUNT>(pr[0], pr[1], pr[2], pr[3], pr[4], first, count, t, stack, cnt);
+    }
     if (count != 0) {
         const ScenePtr<GLOBAL> pr{view.prims + 3 * (size_t)first};
         return leaf_prim_visit<COUNT>(pr[0], pr[1], pr[2], first, count, t, stack, cnt);
@@ -1937,7 +2006,7 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
 #endif
 template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
-    if (PYR_UNIFIED_FETCH && view.wide) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
+    if (PYR_UNIFIED_FETCH && view.wide && view.pairs == nullptr) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
     const bool at_node = t.node >= 0;
     const unsigned long long nodes = __ballot(active && at_node), leaves = __ballot(active && !at_node);
     if (PYR_VOTE_BOTH > 64) {
@@ -2596,8 +2665,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
     stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
-    const SceneView view = S.wide_nodes ? SceneView{reinterpret_cast<const float4*>(S.wide_nodes), reinterpret_cast<const float4*>(S.prims), true}
-                                        : SceneView{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), false};
+    const SceneView view = wide_or_binary_view(S);
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
     bool busy = false;
@@ -2981,8 +3049,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
     stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)stack_lds;
     Counters cnt{};
-    const SceneView view = S.wide_nodes ? SceneView{reinterpret_cast<const float4*>(S.wide_nodes), reinterpret_cast<const float4*>(S.prims), true}
-                                        : SceneView{reinterpret_cast<const float4*>(S.nodes), reinterpret_cast<const float4*>(S.prims), false};
+    const SceneView view = wide_or_binary_view(S);
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
     const size_t n = P.n;
