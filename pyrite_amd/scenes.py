@@ -50,7 +50,9 @@ def _simple(pixel_samples, **kw):
     return renderer.simple(pixel_samples=pixel_samples, **kw)
 
 
-def c1_spheres(width=256, height=256, pixel_samples=64):
+def c1_spheres(width=256, height=256, pixel_samples=64, reference_lamp=False):
+    """`reference_lamp=True` gives the lamp sphere SURVEY 8(d)'s material -- cornell.lua:4-7's `emissive + diffuse` -- instead of
+    the purely emissive one the config uses (see the comment at the lamp below): a parity case, not a workload."""
     m = cornell_materials()
     R = 100.0
     x0, x1, y1, z0, z1 = -5.56, 0.0, 5.592, 0.0, 5.488
@@ -67,7 +69,8 @@ def c1_spheres(width=256, height=256, pixel_samples=64):
         # light material a diffuse hit ON a spherical lamp samples that lamp from its own surface, where
         # solid_angle_towards returns None (shapes/mod.rs:253-271) and lamp.rs:63-66 falls back to area / distance^2 with
         # distance ~ 0: unbounded weights (fireflies of 1e12+) that are a reference quirk, not a useful parity workload.
-        shape.sphere(position=vector(-2.78, 2.795, 4.9), radius=0.5, material={"surface": material.emissive(color=cornell_spectra()["lamp"] * 3)}),
+        shape.sphere(position=vector(-2.78, 2.795, 4.9), radius=0.5,
+                     material=m["light"] if reference_lamp else {"surface": material.emissive(color=cornell_spectra()["lamp"] * 3)}),
     ]
     return {
         "image": {"width": width, "height": height},

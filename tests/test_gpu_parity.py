@@ -425,6 +425,25 @@ def test_tape_records_the_bound_and_no_more(gpu_lib, monkeypatch):
         assert_parity(gfilm, cfilm)
 
 
+@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
+def test_c1_with_the_reference_shaped_lamp_material(scheduler, gpu_lib, monkeypatch):
+    """SURVEY 8(d) writes C1's lamp sphere as cornell.lua's `emissive + diffuse`. The config itself uses a purely emissive lamp
+    (a diffuse hit ON a spherical lamp samples that lamp from its own surface: solid_angle_towards is None there and
+    lamp.rs:63-66 falls back to area / distance^2 with distance ~ 0 -- fireflies of 1e12 and more, a reference quirk that makes
+    the workload useless). This keeps the reference-shaped material as a parity case, so that branch -- sample_towards from
+    inside the shrunken radius, the area / d^2 weight with d ~ 0 -- runs on the GPU and agrees with the oracle, fireflies and all."""
+    monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
+    gfilm, cfilm, gcount, ccount = render_both(scenes.c1_spheres(64, 64, 8, reference_lamp=True), 6, gpu_lib)
+    assert np.array_equal(gfilm.grains[..., 1], cfilm.grains[..., 1])
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+    finite = np.isfinite(cfilm.grains[..., 0])
+    assert np.array_equal(np.isfinite(gfilm.grains[..., 0]), finite)  # the same grains blew up, if any did
+    g, c = np.where(finite, gfilm.grains[..., 0], 0.0), np.where(finite, cfilm.grains[..., 0], 0.0)
+    assert np.allclose(g, c, rtol=2e-5, atol=1e-12)
+    assert c.max() > 1e3 * np.median(c[c > 0])  # the quirk is there: some grain holds a firefly
+
+
 def test_tape_overflow_is_an_error_not_a_wrong_film(gpu_lib, monkeypatch):
     """If a path ever wants more records than the tape's bound (a future change to the next-event count, say), the render
     must fail: the switch below shrinks the tape under the bound to show the overflow word reach the caller."""
