@@ -1679,8 +1679,9 @@ struct Trav { // resumable World::intersect
 
 // Puts a query whose ray, limit and plane results are set at the root of the tree.
 DEV float shadow_cutoff(float limit) { return sqrtf(limit * 1.001f + 1.0e-3f); } // +inf stays +inf; a negative limit gives NaN: nothing passes
+// (t.inv is NOT set here: the kernels compute it where a ray is about to be stepped -- the stage scheduler at every entry of
+// its traversal phase -- so that the three registers are free while the other phases run.)
 DEV void trav_restart(Trav& t) {
-    t.inv = box_reciprocal(t.d);
     if (t.shadow) t.closest = shadow_cutoff(t.limit);
     t.blocked = false;
     t.node = 0;
@@ -2083,10 +2084,16 @@ struct Walker {
     Path p{};
     Trav t{};
     // context of the bounce in flight (between SHADE and the end of its next-event estimation)
-    f3 b_position = mk(0, 0, 0), b_normal = mk(0, 0, 0), b_out = mk(0, 0, 0), b_nff = mk(0, 0, 0);
+    f3 b_position = mk(0, 0, 0), b_normal = mk(0, 0, 0), b_out = mk(0, 0, 0);
+    bool b_flip = false; // the face-forwarded normal of trace_direct (tracer.rs:359-363) is -b_normal
+    DEV f3 b_nff() const { return b_flip ? -b_normal : b_normal; }
     bool b_has_brdf = false;
     uint32_t nee_lamp = 0, nee_i = 0;
-    float nee_probability = 0.0f;
+    // 1 / (samples * 2 pi * p_lamp), tracer.rs:365: a function of the launch alone, formed where it is used
+    DEV static float nee_probability(const DevScene& S, const RenderLaunch& L) {
+        const float lamp_probability = 1.0f / (float)S.num_lamps;
+        return 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+    }
     // the light sample whose shadow ray is in flight
     bool ls_pending = false, ls_physical = false;
     uint32_t ls_material = 0, ls_color = 0;
@@ -2269,9 +2276,7 @@ struct Walker {
                 p.events += 1;
                 if (S.num_lamps > 0) {
                     nee_lamp = rng_range_usize(p.rng, S.num_lamps); // pick_lamp, world.rs:301-305
-                    const float lamp_probability = 1.0f / (float)S.num_lamps;
-                    b_nff = dot(ray_d, normal) < 0.0f ? normal : -normal;
-                    nee_probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * lamp_probability);
+                    b_flip = !(dot(ray_d, normal) < 0.0f);
                     nee_i = 0;
                     ls_pending = false;
                     nee = true;
@@ -2331,11 +2336,11 @@ struct Walker {
         while (nee_i < L.light_samples) {
             const LampSample ls = lamp_sample<INTERP>(lamp, p.rng, b_position);
             nee_i++;
-            const float cos_out = fmaxf(dot(b_nff, ls.direction), 0.0f);
+            const float cos_out = fmaxf(dot(b_nff(), ls.direction), 0.0f);
             if (!(cos_out > 0.0f)) continue;
             if (COUNT) cnt.shadow_rays++;
             const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
-            ls_scale = ls.weight * nee_probability * (2.0f * fabsf(dot(ls.direction, b_nff)));
+            ls_scale = ls.weight * nee_probability(S, L) * (2.0f * fabsf(dot(ls.direction, b_nff())));
             ls_physical = ls.physical;
             ls_material = ls.material;
             ls_color = ls.color;
@@ -2611,6 +2616,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
 #ifdef PYR_PHASE_PROFILE
             const unsigned long long prof_t0_3 = clock64();
 #endif
+            w.t.inv = box_reciprocal(w.t.d); // 1 / direction for the box tests, live in this phase only
             for (int step = 0; step < trav_steps; ++step) {
                 PROF_LANES(3, w.stage == ST_TRAV);
                 if (trav_step_voted<COUNT, !LDS_SCENE>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
@@ -2685,6 +2691,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
                     ray = feed.next + rank;
                     const float* r = L.rays + 6 * (size_t)ray;
                     trav_begin<COUNT>(S, t, ld3(r), ld3(r + 3), false, 0.0f, cnt);
+                    t.inv = box_reciprocal(t.d);
                     busy = true;
                 }
                 feed.next += min((uint32_t)idle, available);
@@ -2760,11 +2767,12 @@ DEV void wf_load(const WfPool& P, uint32_t slot, uint32_t word, bool planes, Wal
     w.nee_i = __float_as_uint(g0.w);
     w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
     w.p.pixel = __float_as_uint(g2.x), w.p.wl = g2.z, w.p.bright = g2.w;
-    w.p.refl = g3.x, w.nee_probability = g3.y, w.ls_scale = g3.z, w.ls_color = __float_as_uint(g3.w);
+    w.p.refl = g3.x, w.ls_scale = g3.z, w.ls_color = __float_as_uint(g3.w);
     w.t.d = xyz(g5), w.ls_material = __float_as_uint(g5.w);
     if (w.stage == ST_NEE) {
         const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n], g10 = g[10 * n], g11 = g[11 * n];
-        w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9), w.b_nff = xyz(g10), w.ls_normal = xyz(g11);
+        w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9), w.ls_normal = xyz(g11);
+        w.b_flip = __float_as_uint(g9.w) != 0u;
         w.ls_tx = g10.w, w.ls_ty = g11.w;
         w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event)
     } else {
@@ -2796,18 +2804,18 @@ DEV void wf_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUN
     if (w.stage == ST_DONE) return;
     g[1 * n] = make_float4(__uint_as_float(w.p.rng.x), __uint_as_float(w.p.rng.y), __uint_as_float(w.p.rng.z), __uint_as_float(w.p.rng.w));
     g[2 * n] = make_float4(__uint_as_float(w.p.pixel), 0.0f, w.p.wl, w.p.bright);
-    g[3 * n] = make_float4(w.p.refl, w.nee_probability, w.ls_scale, __uint_as_float(w.ls_color));
+    g[3 * n] = make_float4(w.p.refl, 0.0f, w.ls_scale, __uint_as_float(w.ls_color));
     g[4 * n] = mk4(w.t.o, w.t.limit);
     g[5 * n] = mk4(w.t.d, __uint_as_float(w.ls_material));
     if (planes) g[6 * n] = make_float4(w.t.closest, __uint_as_float(w.t.shape), w.t.u, w.t.v);
     if (w.touched & TOUCH_SHADE) {
         g[7 * n] = mk4(w.b_position, 0.0f);
         g[8 * n] = mk4(w.b_normal, 0.0f);
-        g[9 * n] = mk4(w.b_out, 0.0f);
-        g[10 * n] = mk4(w.b_nff, 0.0f);
+        g[9 * n] = mk4(w.b_out, __uint_as_float(w.b_flip ? 1u : 0u));
+        g[10 * n] = mk4(w.b_nff(), 0.0f);
     }
     if (w.touched & TOUCH_LIGHT) g[11 * n] = mk4(w.ls_normal, w.ls_ty);
-    if (INTERP && (w.touched & TOUCH_LIGHT)) g[10 * n] = mk4(w.b_nff, w.ls_tx); // the light sample's texture coordinates ride in the spare lanes
+    if (INTERP && (w.touched & TOUCH_LIGHT)) g[10 * n] = mk4(w.b_nff(), w.ls_tx); // the light sample's texture coordinates ride in the spare lanes
     float* c = P.companions + slot;
     if (w.touched & TOUCH_NEW)
         for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(0 * n_comp + k) * n] = spec.wl(k);
@@ -2924,12 +2932,10 @@ DEV void wft_load(const DevScene& S, const RenderLaunch& L, const WfPool& P, uin
     w.nee_i = nee >> 16;
     w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
     w.ls_scale = g2.y, w.ls_color = __float_as_uint(g2.z), w.ls_material = __float_as_uint(g2.w);
-    // shade()'s own expression (tracer.rs:365): the same operations on the same launch constants give the same bits
-    w.nee_probability = 1.0f / ((float)L.light_samples * 2.0f * PI_F * (1.0f / (float)S.num_lamps));
     if (w.stage == ST_NEE) {
         const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n];
         w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9);
-        w.b_nff = (packed & WFT_FLAG_NFF_FLIPPED) ? -w.b_normal : w.b_normal;
+        w.b_flip = (packed & WFT_FLAG_NFF_FLIPPED) != 0;
         w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event); its direction is not read again
     } else {
         const float4 g4 = g[4 * n], g5 = g[5 * n], g6 = g[6 * n];
@@ -2943,8 +2949,7 @@ template <bool COUNT>
 DEV void wft_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUNT, false, true>& w, Spectral& spec, uint32_t n_comp) {
     float4* g = reinterpret_cast<float4*>(P.groups) + slot;
     const size_t n = P.n;
-    // b_nff is b_normal or its negation (shade: dot(ray_d, normal) < 0 ? normal : -normal): the sign of any non-zero component tells
-    const bool flipped = (w.b_nff.x != w.b_normal.x) | (w.b_nff.y != w.b_normal.y) | (w.b_nff.z != w.b_normal.z);
+    const bool flipped = w.b_flip;
     const uint32_t packed = (w.p.bounce & 0xfffu) | ((w.n_ops & 0xfffu) << 12) | ((w.p.events & 3u) << 24) | (w.p.use_additional ? WFT_FLAG_ADDITIONAL : 0u) |
                             (w.p.sample_light ? WFT_FLAG_SAMPLE_LIGHT : 0u) | (w.b_has_brdf ? WFT_FLAG_HAS_BRDF : 0u) | (w.ls_pending ? WFT_FLAG_LS_PENDING : 0u) |
                             (w.ls_physical ? WFT_FLAG_LS_PHYSICAL : 0u) | (flipped ? WFT_FLAG_NFF_FLIPPED : 0u);
@@ -3081,6 +3086,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
                             t.closest = g6.x, t.shape = __float_as_uint(g6.y), t.u = g6.z, t.v = g6.w;
                         }
                         trav_restart(t);
+                        t.inv = box_reciprocal(t.d);
                         busy = true;
                     }
                 }

@@ -20,7 +20,7 @@ PMC="--pmc"
 if [ "${ONLY:-all}" = "all" ] || [ "$ONLY" = "bench" ]; then
   T0=$(date +%s.%N)
   timeout -k 10 900 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/c3_bench.json 2> $OUT/c3_bench.err; rc=$?
-  echo "$(echo "$(date +%s.%N) - $T0" | bc) s wall" > $OUT/c3_bench.wall; echo "[bench C3 driver args] rc=$rc $(cat $OUT/c3_bench.wall)"
+  python3 -c "import time,sys; print(\"%.1f s wall\" % (time.time() - float(sys.argv[1])))" $T0 > $OUT/c3_bench.wall; echo "[bench C3 driver args] rc=$rc $(cat $OUT/c3_bench.wall)"
 fi
 if [ "${ONLY:-all}" = "all" ] || [ "$ONLY" = "c3" ]; then
   step c3_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_trace -o c3 -- python3 $R/bench.py $C3 --steps 2 --warmup 0
