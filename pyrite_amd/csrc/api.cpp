@@ -448,6 +448,12 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
                 if (code >= 0 || code == kEmptyChild) continue;
                 const uint32_t first = (uint32_t)(-1 - code) >> 3, count = (uint32_t)(-1 - code) & 7u;
                 node.child[k] = encode_leaf((uint32_t)pairs.size(), count);
+                if (count == 0) { // an empty leaf still names a record (trav_step_lean loads it before it looks at the count): one no triangle passes
+                    DevPrimPair none;
+                    std::memset(&none, 0, sizeof(none));
+                    none.q[1][2] = none.q[1][3] = shape_bits(PYR_HIT_NONE);
+                    pairs.push_back(none);
+                }
                 for (uint32_t j = 0; j < count; j += 2) {
                     DevPrimPair pr;
                     std::memset(&pr, 0, sizeof(pr));

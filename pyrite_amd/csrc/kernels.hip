@@ -1675,7 +1675,9 @@ struct Trav { // resumable World::intersect
     uint32_t shape;
     float u, v;
     bool shadow, blocked;
+    int parked = 0; // trav_step_postponed: the code of a leaf the lane has walked into and not tested yet (0: none)
 };
+constexpr int kNoNode = INT32_MIN; // trav_step_postponed: t.node when the lane holds no subtree any more (never a leaf code: api.cpp keeps first + count < 2^28)
 
 // Puts a query whose ray, limit and plane results are set at the root of the tree.
 DEV float shadow_cutoff(float limit) { return sqrtf(limit * 1.001f + 1.0e-3f); } // +inf stays +inf; a negative limit gives NaN: nothing passes
@@ -1686,6 +1688,7 @@ DEV void trav_restart(Trav& t) {
     t.blocked = false;
     t.node = 0;
     t.sp = 0;
+    t.parked = 0;
 }
 
 // Planes first (world.rs:277-285), then the tree from the root. Returns true when the query is already decided.
@@ -1742,14 +1745,15 @@ struct TravStack {
 // One visit of a four-child node (bvh.h Node128). The twelve plane distances of two children at a time are v_pk_fma_f32;
 // the children that are hit are ordered by entry distance with a five-comparator network, the nearest is entered and the
 // others are pushed far to near, so they pop nearest first. Returns true when the traversal has finished.
+// The four box tests of a node and the order of its children: c[] = the children that are hit, nearest first (entry distance
+// e[]), the others INT32_MIN at the end.
 template <bool COUNT>
-DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, Trav& t,
-                         TravStack& stack, Counters& cnt) {
+DEV void wide_node_children(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, const Trav& t,
+                            Counters& cnt, float (&e)[4], int (&c)[4]) {
     const f2v ix = {t.inv.x, t.inv.x}, iy = {t.inv.y, t.inv.y}, iz = {t.inv.z, t.inv.z};
     const float ox = -(t.o.x * t.inv.x), oy = -(t.o.y * t.inv.y), oz = -(t.o.z * t.inv.z);
     const f2v nox = {ox, ox}, noy = {oy, oy}, noz = {oz, oz};
-    float e[4];
-    int c[4] = {__float_as_int(ch.x), __float_as_int(ch.y), __float_as_int(ch.z), __float_as_int(ch.w)};
+    c[0] = __float_as_int(ch.x), c[1] = __float_as_int(ch.y), c[2] = __float_as_int(ch.z), c[3] = __float_as_int(ch.w);
     {
         const f2v alx = __builtin_elementwise_fma((f2v){lx.x, lx.y}, ix, nox), ahx = __builtin_elementwise_fma((f2v){hx.x, hx.y}, ix, nox);
         const f2v aly = __builtin_elementwise_fma((f2v){ly.x, ly.y}, iy, noy), ahy = __builtin_elementwise_fma((f2v){hy.x, hy.y}, iy, noy);
@@ -1784,8 +1788,18 @@ DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, cons
     order(0, 2);
     order(1, 3);
     order(1, 2);
+}
+template <bool COUNT, bool POSTPONE = false>
+DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, Trav& t,
+                         TravStack& stack, Counters& cnt) {
+    float e[4];
+    int c[4];
+    wide_node_children<COUNT>(lx, ly, lz, hx, hy, hz, ch, t, cnt, e, c);
     if (c[0] == INT32_MIN) { // nothing hit
-        if (t.sp == 0) return true;
+        if (t.sp == 0) {
+            if (POSTPONE) t.node = kNoNode;
+            return true;
+        }
         t.sp--;
         t.node = stack.pop(t.sp);
         return false;
@@ -1820,8 +1834,9 @@ DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counte
 
 // One primitive of a leaf, its record already loaded (a, b, c = the three vectors of a DevPrim): the tests and the
 // bookkeeping of trav_step's leaf part. `first` / `count` are the leaf code's fields. Returns true when the traversal has finished.
+// The test and the verdict; true when the primitive blocks a shadow ray.
 template <bool COUNT>
-DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_t first, uint32_t count, Trav& t, TravStack& stack, Counters& cnt) {
+DEV bool leaf_prim_test(const float4 a, const float4 b, const float4 c, Trav& t, Counters& cnt) {
     const uint32_t shape = __float_as_uint(a.w);
     float dist = 0.0f, u = 0.0f, v = 0.0f;
     bool ok;
@@ -1842,7 +1857,11 @@ DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_
     t.shape = closer ? shape : t.shape;
     t.u = closer ? u : t.u;
     t.v = closer ? v : t.v;
-    if (blocks) return true;
+    return blocks;
+}
+template <bool COUNT>
+DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_t first, uint32_t count, Trav& t, TravStack& stack, Counters& cnt) {
+    if (leaf_prim_test<COUNT>(a, b, c, t, cnt)) return true;
     if (count > 1) {
         t.node = -1 - (int)(((first + 1) << 3) | (count - 1));
         return false;
@@ -1928,8 +1947,7 @@ DEV bool trav_node_step(const SceneView& view, Trav& t, TravStack& stack, Counte
 // against 4.5 node visits; with pairs it makes ~1.9, the wave's vote goes to the node kind more often and finds more lanes
 // there, and a pair costs ~1.3 single tests.
 template <bool COUNT>
-DEV bool leaf_pair_visit(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4, uint32_t first, uint32_t count, Trav& t,
-                         TravStack& stack, Counters& cnt) {
+DEV bool leaf_pair_test(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4, uint32_t count, Trav& t, Counters& cnt) {
     const f2v v1x = {q0.x, q0.y}, v1y = {q0.z, q0.w}, v1z = {q1.x, q1.y};
     const f2v e1x = {q2.x, q2.y}, e1y = {q2.z, q2.w}, e1z = {q3.x, q3.y};
     const f2v e2x = {q3.z, q3.w}, e2y = {q4.x, q4.y}, e2z = {q4.z, q4.w};
@@ -1960,7 +1978,12 @@ DEV bool leaf_pair_visit(const float4 q0, const float4 q1, const float4 q2, cons
     t.shape = closer_b ? shape_b : (closer_a ? shape_a : t.shape);
     t.u = closer_b ? u.y : (closer_a ? u.x : t.u);
     t.v = closer_b ? v.y : (closer_a ? v.x : t.v);
-    if (blocks) return true;
+    return blocks;
+}
+template <bool COUNT>
+DEV bool leaf_pair_visit(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4, uint32_t first, uint32_t count, Trav& t,
+                         TravStack& stack, Counters& cnt) {
+    if (leaf_pair_test<COUNT>(q0, q1, q2, q3, q4, count, t, cnt)) return true;
     if (count > 2u) {
         t.node = -1 - (int)(((first + 1u) << 3) | (count - 2u));
         return false;
@@ -1993,6 +2016,74 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
     return t.node >= 0 ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : trav_leaf_step<COUNT, GLOBAL>(view, t, stack, cnt);
 }
 
+// The vote of trav_step_voted leaves the lanes of the other kind idle for the step. Here a lane that walks into a leaf parks
+// the leaf (t.parked) and goes on with the next subtree on its stack, so it takes part in the node steps until it walks into a
+// second leaf, and the leaf step finds the lanes that have parked one in the meantime (speculative traversal in the sense of
+// Aila & Laine 2009). The boxes visited while a leaf is parked are tested against the closest hit the leaf has not improved
+// yet: a few more node visits, no other result -- the closest hit is a minimum and a shadow ray's verdict an `or`, whatever
+// the order (equal distances excepted: the first one found keeps the hit, as everywhere). Wide trees only.
+#ifndef PYR_LEAF_WEIGHT
+#define PYR_LEAF_WEIGHT 100 // the leaf step runs when lanes_with_a_parked_leaf * 100 >= lanes_at_a_node * PYR_LEAF_WEIGHT
+#endif
+template <bool COUNT>
+DEV bool trav_step_postponed(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
+    if (active && t.node < 0 && t.node != kNoNode && t.parked == 0) {
+        t.parked = t.node;
+        if (t.sp == 0) {
+            t.node = kNoNode;
+        } else {
+            t.sp--;
+            t.node = stack.pop(t.sp);
+        }
+    }
+    const bool want_node = active && t.node >= 0, want_leaf = active && t.parked != 0;
+    const int n_node = __popcll(__ballot(want_node)), n_leaf = __popcll(__ballot(want_leaf));
+    if (n_leaf * 100 >= n_node * PYR_LEAF_WEIGHT) {
+        if (want_leaf) {
+            const uint32_t code = (uint32_t)(-1 - t.parked);
+            const uint32_t first = code >> 3, count = code & 7u;
+            bool blocks = false;
+            uint32_t left = 0;
+            if (view.pairs != nullptr) {
+                if (count != 0) {
+                    const ScenePtr<true> pr{view.pairs + 5 * (size_t)first};
+                    blocks = leaf_pair_test<COUNT>(pr[0], pr[1], pr[2], pr[3], pr[4], count, t, cnt);
+                }
+                left = count > 2u ? count - 2u : 0u;
+            } else {
+                if (count != 0) {
+                    const ScenePtr<true> pr{view.prims + 3 * (size_t)first};
+                    blocks = leaf_prim_test<COUNT>(pr[0], pr[1], pr[2], t, cnt);
+                }
+                left = count > 1u ? count - 1u : 0u;
+            }
+            t.parked = left != 0 ? -1 - (int)(((first + 1u) << 3) | left) : 0;
+            if (blocks) {
+                t.parked = 0;
+                t.node = kNoNode;
+                t.sp = 0;
+            }
+        }
+    } else if (want_node) {
+        const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
+        wide_node_visit<COUNT, true>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
+    }
+    return active && t.node == kNoNode && t.parked == 0;
+}
+
+// The step of trav_step_voted (majority kind only) for the tree the big scenes walk -- four-child nodes whose leaves index
+// triangle pairs -- as straight-line code. What the generic step spends around the tests is control flow: three conditional
+// pushes, each an LDS-or-scratch choice (two saved exec masks and their branches per push), the same again around the pop, and
+// the exits of the leaf. Here, as long as no lane of the wave is within three levels of the end of its LDS stack (a wave-uniform
+// test; otherwise the generic step runs, same results):
+//   - the top of the stack is read when the step begins, next to the node's loads, whether or not it will be popped;
+//   - the children that are hit are a prefix of the sorted four, so child k goes to level sp + n - k, and a child that is NOT
+//     hit is stored too -- at level sp + n, above the new top, where nothing lives;
+//   - node, stack pointer and the verdict are selects.
+// Same tests, same order of visits, same stack contents below the top as the generic step.
+DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); } // the mask itself: __ballot() goes through an integer and back
+template <bool COUNT>
+DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active);
 // One step for the lanes of a wave that have a ray in flight (`active`), with a vote: a step is an inner-node visit or a
 // primitive test, two different pieces of code, and a wave whose lanes want both runs both at partial occupancy. When fewer
 // than PYR_VOTE_BOTH lanes want the minority kind, only the majority kind runs this turn and the minority keeps its place
@@ -2005,8 +2096,17 @@ DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& c
 #ifndef PYR_UNIFIED_FETCH
 #define PYR_UNIFIED_FETCH 0
 #endif
-template <bool COUNT, bool GLOBAL = true>
+#ifndef PYR_POSTPONE_LEAF
+#define PYR_POSTPONE_LEAF 0
+#endif
+#ifndef PYR_LEAN_STEP
+#define PYR_LEAN_STEP 1
+#endif
+template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
+    if constexpr (POSTPONE && GLOBAL) {
+        if (view.wide) return trav_step_postponed<COUNT>(view, t, stack, cnt, active);
+    }
     if (PYR_UNIFIED_FETCH && view.wide && view.pairs == nullptr) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
     const bool at_node = t.node >= 0;
     const unsigned long long nodes = __ballot(active && at_node), leaves = __ballot(active && !at_node);
@@ -2022,6 +2122,47 @@ DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Count
         if (active && !(at_node ? run_node : run_leaf)) active = false;
     }
     return active && trav_step<COUNT, GLOBAL>(view, t, stack, cnt);
+}
+
+template <bool COUNT>
+DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
+    const bool at_node = t.node >= 0;
+    const unsigned long long nodes = ballot64(active && at_node), leaves = ballot64(active && !at_node);
+    if (ballot64(active && t.sp + 3 > stack.lds_entries) != 0ull) { // somebody's stack is about to leave LDS: the generic step
+        if (__builtin_popcountll(nodes) >= __builtin_popcountll(leaves)) return (active && at_node) ? trav_node_step<COUNT, true>(view, t, stack, cnt) : false;
+        return (active && !at_node) ? trav_leaf_step<COUNT, true>(view, t, stack, cnt) : false;
+    }
+    bool done = false;
+    const int below = max(t.sp - 1, 0);
+    if (__builtin_popcountll(nodes) >= __builtin_popcountll(leaves)) {
+        if (active && at_node) {
+            const int top = stack.lds[below * BLOCK];
+            const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
+            float e[4];
+            int c[4];
+            wide_node_children<COUNT>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, cnt, e, c);
+            const bool none = c[0] == INT32_MIN, hit1 = c[1] != INT32_MIN, hit2 = c[2] != INT32_MIN, hit3 = c[3] != INT32_MIN;
+            const int n = (hit1 ? 1 : 0) + (hit2 ? 1 : 0) + (hit3 ? 1 : 0); // children to push: c[1 .. n], far to near
+            const int above = t.sp + n;
+            stack.lds[(hit3 ? t.sp : above) * BLOCK] = c[3]; // hit3 means n == 3: c[3] is the farthest, at the bottom
+            stack.lds[(hit2 ? above - 2 : above) * BLOCK] = c[2];
+            stack.lds[(hit1 ? above - 1 : above) * BLOCK] = c[1];
+            done = none & (t.sp == 0);
+            t.node = none ? top : c[0];
+            t.sp = none ? below : above;
+        }
+    } else if (active && !at_node) {
+        const int top = stack.lds[below * BLOCK];
+        const uint32_t code = (uint32_t)(-1 - t.node);
+        const uint32_t first = code >> 3, count = code & 7u;
+        const ScenePtr<true> pr{view.pairs + 5 * (size_t)first};
+        const bool blocks = leaf_pair_test<COUNT>(pr[0], pr[1], pr[2], pr[3], pr[4], count, t, cnt);
+        const bool more = count > 2u;
+        done = blocks | (!more & (t.sp == 0));
+        t.node = more ? -1 - (int)(((first + 1u) << 3) | (count - 2u)) : top;
+        t.sp = more ? t.sp : below;
+    }
+    return done;
 }
 
 // Per-path state of the resumable integrator and the code of its phases; shared by the stage-scheduled kernel (state in
@@ -2375,18 +2516,30 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     // The finished lanes are listed with the paths that keep their companions first, the dispersed ones behind them: a
     // dispersed path exposes its hero wavelength only (simple.rs:133-139), so it is ONE item, not S of which S - 1 idle --
     // on C5 a third of the paths disperse and a turn's items drop from 10 n to ~7 n, often a whole pass of 64 less.
-    const unsigned long long full_mask = __ballot(exposing && p.use_additional);
+    // Within each group the lanes are listed by tape length, long tapes first (three classes: above 2/3 of the longest, above
+    // 1/3, the rest): a pass of 64 items walks as many rows as ITS longest tape has, and a path that left the scene after two
+    // bounces has a fifth of the records of one that made all eight -- listed in lane order every pass held a long one.
+    uint32_t max_ops = exposing ? (n_ops < L.tape_max_ops ? n_ops : L.tape_max_ops) : 0u;
+    const uint32_t my_ops = max_ops;
+    for (int off = 32; off > 0; off >>= 1) max_ops = max(max_ops, (uint32_t)__shfl_xor((int)max_ops, off));
+    const bool keeps = exposing && p.use_additional, lost = exposing && !p.use_additional;
+    const bool longest = 3u * my_ops > 2u * max_ops, shortest = 3u * my_ops <= max_ops;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const uint32_t n_full = (uint32_t)__popcll(full_mask);
-    if (exposing) wave_list[p.use_additional ? __popcll(full_mask & below) : n_full + __popcll(mask & ~full_mask & below)] = lane;
+    const unsigned long long k0 = ballot64(keeps && longest), k1 = ballot64(keeps && !longest && !shortest), k2 = ballot64(keeps && shortest);
+    const unsigned long long l0 = ballot64(lost && longest), l1 = ballot64(lost && !longest && !shortest), l2 = ballot64(lost && shortest);
+    const uint32_t n_full = (uint32_t)__builtin_popcountll(k0 | k1 | k2);
+    if (exposing) {
+        const unsigned long long mine = keeps ? (longest ? k0 : (shortest ? k2 : k1)) : (longest ? l0 : (shortest ? l2 : l1));
+        uint32_t before = keeps ? 0u : n_full;
+        before += (uint32_t)__builtin_popcountll(keeps ? ((longest ? 0ull : k0) | (shortest ? k1 : 0ull)) : ((longest ? 0ull : l0) | (shortest ? l1 : 0ull)));
+        wave_list[before + (uint32_t)__builtin_popcountll(mine & below)] = lane;
+    }
     __builtin_amdgcn_wave_barrier();
     const uint32_t SS = L.spectrum_samples, full_items = n_full * SS, items = full_items + (n - n_full);
-    // Longest tape among the finished lanes. The wave reads the tape row by row: a row (one record index of all 64 lanes) is 512
-    // contiguous bytes, so every lane loads its own column's record -- one coalesced load per row, eight rows in flight -- and
-    // an item takes the record of the lane it replays with a cross-lane read. (Reading record after record of one column from
-    // the item's lane was a chain of dependent HBM round trips: it took a quarter of the render.)
-    uint32_t max_ops = exposing ? (n_ops < L.tape_max_ops ? n_ops : L.tape_max_ops) : 0u;
-    for (int off = 32; off > 0; off >>= 1) max_ops = max(max_ops, (uint32_t)__shfl_xor((int)max_ops, off));
+    // The wave reads the tape row by row: a row (one record index of all 64 lanes) is 512 contiguous bytes, so every finished
+    // lane loads its own column's record -- one coalesced load per row, eight rows in flight -- and an item takes the record of
+    // the lane it replays with a cross-lane read. (Reading record after record of one column from the item's lane was a chain
+    // of dependent HBM round trips: it took a quarter of the render.) Lanes that are not being replayed load nothing.
     const unsigned long long* my_column = L.tape + tape_column;
 #ifndef PYR_REPLAY_ROWS
 #define PYR_REPLAY_ROWS 8
@@ -2399,13 +2552,9 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         const uint32_t rank = !active ? 0u : (full ? i / SS : n_full + (i - full_items)), k = !active ? 0u : (full ? i - rank * SS : SS - 1u);
         const uint32_t src = wave_list[rank];
         const uint32_t ops = (uint32_t)__shfl((int)n_ops, (int)src);
-#ifdef PYR_REPLAY_PASS_MAX
-        // the rows this pass needs: the longest tape among ITS items (finished lanes are listed in lane order, not by length)
+        // the rows this pass needs: the longest tape among ITS items
         uint32_t pass_ops = active ? (ops < L.tape_max_ops ? ops : L.tape_max_ops) : 0u;
         for (int off = 32; off > 0; off >>= 1) pass_ops = max(pass_ops, (uint32_t)__shfl_xor((int)pass_ops, off));
-#else
-        const uint32_t pass_ops = max_ops;
-#endif
         const uint32_t pixel = (uint32_t)__shfl((int)p.pixel, (int)src);
         const float hero_wl = __shfl(p.wl, (int)src);
         const bool hero = k == SS - 1;
@@ -2433,7 +2582,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
             unsigned long long rows[ROWS];
 #pragma unroll
-            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < pass_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
+            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < my_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
             // all cross-lane reads of the batch first (one wait), then, in the eager form, all value reads (one more)
             uint32_t words[ROWS];
             float factors[ROWS];
@@ -2617,9 +2766,16 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
             const unsigned long long prof_t0_3 = clock64();
 #endif
             w.t.inv = box_reciprocal(w.t.d); // 1 / direction for the box tests, live in this phase only
-            for (int step = 0; step < trav_steps; ++step) {
-                PROF_LANES(3, w.stage == ST_TRAV);
-                if (trav_step_voted<COUNT, !LDS_SCENE>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+            if (!LDS_SCENE && PYR_LEAN_STEP && !PYR_POSTPONE_LEAF && view.wide && view.pairs != nullptr) {
+                for (int step = 0; step < trav_steps; ++step) {
+                    PROF_LANES(3, w.stage == ST_TRAV);
+                    if (trav_step_lean<COUNT>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+                }
+            } else {
+                for (int step = 0; step < trav_steps; ++step) {
+                    PROF_LANES(3, w.stage == ST_TRAV);
+                    if (trav_step_voted<COUNT, !LDS_SCENE, PYR_POSTPONE_LEAF != 0>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+                }
             }
             PROF_END(3);
         }
