@@ -664,6 +664,8 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 0;
     else if (e && std::string(e) == "wf")
         L.scheduler = 2;
+    else if (e && std::string(e) == "split")
+        L.scheduler = 3;
     else
         L.scheduler = scene_is_lds_resident(scene->dev) ? 0u : 1u;
     // texture coordinates and normal maps live in the resumable integrator (Walker); the synchronous walk has no texture path
@@ -687,7 +689,7 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;
-    if (L.scheduler == 1 && scene->dev.needs_interpreter == 0) {
+    if ((L.scheduler == 1 || L.scheduler == 3) && scene->dev.needs_interpreter == 0) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
         L.tape_max_ops = tape_ops_bound(L);
         int rc = reserve_tape(scene, L, stream);
@@ -705,6 +707,7 @@ int check_tape_overflow(PyrScene* scene) {
     HIP_TRY(hipMemcpy(&word, scene->tape_overflow.ptr, sizeof(word), hipMemcpyDeviceToHost));
     if (word == 0) return PYR_OK;
     HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
+    if (word == 2) return fail(PYR_ERR_DEVICE, "the split scheduler gave up waiting (a wave polled its LDS slots past the spin limit): the film of that render is invalid");
     return fail(PYR_ERR_DEVICE, "a path appended more records than the spectral tape's bound allows: the film of that render is invalid");
 }
 

@@ -134,7 +134,7 @@ struct RenderLaunch {
     float grains_per_wavelength; // bins / wl_width (film.rs:38)
     PyrGrain* film_out;
     unsigned long long* counters; // 9 words (PyrCounters order) or nullptr
-    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm), 2 = wavefront
+    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm), 2 = wavefront, 3 = split (render_kernel_split)
     uint32_t sm_phase_lanes, sm_trav_steps; // stage scheduler: lanes that make a phase run; traversal steps per turn
     uint32_t sm_expose_lanes;               // finished lanes that make the tape replay run (TAPE builds)
     uint32_t stack_lds; // traversal stack levels kept in LDS (set by launch_render; deeper levels spill to scratch in the sm kernel)

@@ -1647,6 +1647,8 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
 #define PROF_BEGIN(ph, cond) const unsigned long long prof_t0_##ph = clock64(); prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
 #define PROF_END(ph) prof_c[ph] += clock64() - prof_t0_##ph
 #define PROF_LANES(ph, cond) prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
+#define PROF_NOW() clock64()
+#define PROF_EXTRA(idx, cycles) if ((threadIdx.x & 63u) == 0) atomicAdd(&g_phase_prof[idx], (unsigned long long)(cycles))
 #define PROF_FLUSH()                                                                                  \
     if ((threadIdx.x & 63u) == 0)                                                                     \
         for (int i = 0; i < 4; ++i) {                                                                 \
@@ -1659,11 +1661,13 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
 #define PROF_BEGIN(ph, cond)
 #define PROF_END(ph)
 #define PROF_LANES(ph, cond)
+#define PROF_NOW() 0ull
+#define PROF_EXTRA(idx, cycles)
 #define PROF_FLUSH()
 #endif
 
 enum Touched : uint32_t { TOUCH_NEW = 1, TOUCH_BRIGHT = 2, TOUCH_REFL = 4, TOUCH_SHADE = 8, TOUCH_LIGHT = 16 };
-enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EXPOSE = 4, ST_DONE = 5 };
+enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EXPOSE = 4, ST_DONE = 5, ST_WAIT = 6 }; // ST_WAIT: render_kernel_split, the ray is with a traversal wave
 
 struct Trav { // resumable World::intersect
     f3 o, d, inv;
@@ -2687,6 +2691,23 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
     return n_spectral > kTapeEagerSlots ? 0u : n_spectral; // too many for the reserved rows: the replay looks them up record by record
 }
 
+// The launch record as the kernel-argument segment holds it, behind a pointer the compiler cannot see through. The stage
+// loop keeps ~100 uniform scene / launch values alive; there are 104 scalar registers, so the allocator parks the rest in
+// lanes of a VGPR and fetches them back with v_readlane -- vector instructions, sixteen in a row where a phase wants the
+// camera -- in a kernel that is bound by vector issue. Read through this reference at the head of a phase the fields are
+// s_load'ed from the (scalar-cached) argument segment where they are used and die with the phase.
+#ifndef PYR_RELOAD_LAUNCH
+#define PYR_RELOAD_LAUNCH 1
+#endif
+typedef __attribute__((address_space(4))) const RenderLaunch* kernarg_launch_ptr;
+constexpr size_t kLaunchKernargOffset = (sizeof(DevScene) + alignof(RenderLaunch) - 1) / alignof(RenderLaunch) * alignof(RenderLaunch);
+DEV const RenderLaunch& launch_from_kernarg(const RenderLaunch& by_value) {
+    if (!PYR_RELOAD_LAUNCH) return by_value;
+    unsigned long long at = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + kLaunchKernargOffset;
+    asm volatile("" : "+s"(at));
+    return *(const RenderLaunch*)(kernarg_launch_ptr)at;
+}
+
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
@@ -2736,8 +2757,9 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
 
         if (nE >= expose_lanes || nE == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
-            if constexpr (TAPE) replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
-            w.expose_and_restart(S, L, spec, cnt, lane, total_waves);
+            const RenderLaunch& Lp = launch_from_kernarg(L);
+            if constexpr (TAPE) replay_tapes<COUNT>(S, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+            w.expose_and_restart(S, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
             nS = __popcll(__ballot(w.stage == ST_SHADE));
@@ -2745,7 +2767,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         }
         if (nS >= phase_lanes || nS == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(1, w.stage == ST_SHADE);
-            w.shade(S, L, spec, cnt);
+            w.shade(S, launch_from_kernarg(L), spec, cnt);
             PROF_END(1);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
             nN = __popcll(__ballot(w.stage == ST_NEE));
@@ -2754,7 +2776,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         }
         if (nN >= phase_lanes || nN == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(2, w.stage == ST_NEE);
-            w.next_event(S, L, spec, cnt);
+            w.next_event(S, launch_from_kernarg(L), spec, cnt);
             PROF_END(2);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
             nN = __popcll(__ballot(w.stage == ST_NEE));
@@ -2781,6 +2803,240 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         }
     }
     PROF_FLUSH();
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ------------------------------------------------------------------------------------------------ split scheduler
+// render_kernel_split: the stage-scheduled integrator with the waves of a workgroup in two roles. In render_kernel_sm every
+// wave does everything, and every phase finds a fraction of the wave's lanes: on C3 the traversal steps run with 37 of 64
+// lanes holding a ray (the others wait for a shading or light-sampling phase), SHADE and NEE with ~20. Here the first
+// PYR_SPLIT_LOGIC_WAVES waves of a workgroup own the paths (Walker state in registers; they run EXPOSE / SHADE / NEE and never
+// walk the tree) and the other waves only traverse: a logic lane posts its ray in a slot of its own in LDS and waits
+// (ST_WAIT); a traversal wave claims posted rays for its idle lanes (as intersect_kernel takes rays from a batch), steps them
+// with trav_step_lean and writes the hit back. The traversal waves are full whenever rays are waiting, and a logic wave
+// that waits issues nothing, so it can afford to wait until a phase has more lanes (sm_phase_lanes is the quorum while
+// rays are out; after PYR_SPLIT_PATIENCE empty polls the most wanted phase runs with what it has).
+//   Slots: one per logic lane, structure of arrays in the columns of the traversal-stack rows that belong to the logic lanes
+// (they walk no tree): row 0 the state word (EMPTY -> REQUESTED by the owner -> TAKEN by the traversal lane that won the
+// compare-and-swap -> DONE -> read back by the owner), rows 1-10 the ray (origin, direction, limit, the closest hit and shape
+// the planes left, shadow flag), overwritten by the result (closest, shape, u, v, blocked). Data is written before the
+// state word and read after it (LDS is in order per wave; workgroup-scope release / acquire fences keep the compiler honest).
+//   Every path performs the operations of render_kernel_sm in the same order (the Walker phases are shared), so the films
+// are identical. No wave waits for ever: both roles count their empty polls and give up with the launch's error word set.
+#ifndef PYR_SPLIT_LOGIC_WAVES
+#define PYR_SPLIT_LOGIC_WAVES 2
+#endif
+#ifndef PYR_SPLIT_PATIENCE
+#define PYR_SPLIT_PATIENCE 6
+#endif
+#ifndef PYR_SPLIT_SLEEP
+#define PYR_SPLIT_SLEEP 8
+#endif
+#ifndef PYR_SPLIT_REFILL
+#define PYR_SPLIT_REFILL 16
+#endif
+constexpr uint32_t kSplitLogicWaves = PYR_SPLIT_LOGIC_WAVES, kSplitLogicLanes = 64u * kSplitLogicWaves;
+constexpr uint32_t kSplitRows = 11; // LDS rows a slot needs (the kernel wants stack_lds >= this)
+constexpr uint32_t SLOT_EMPTY = 0u, SLOT_REQUESTED = 1u, SLOT_TAKEN = 2u, SLOT_DONE = 3u;
+constexpr uint32_t kSplitSpinLimit = 1u << 22;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+DEV uint32_t slot_load(lds_u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void slot_store(lds_u32* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <bool COUNT, bool LDS_TABLES>
+__global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_split(DevScene S0, RenderLaunch L) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    Spectral spec{lds + threadIdx.x, SS};
+    const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots;
+    int* stack_rows = reinterpret_cast<int*>(lds + spectral_rows * BLOCK);
+    TravStack stack;
+    stack.lds = (lds_int*)(stack_rows + threadIdx.x);
+    stack.lds_entries = (int)L.stack_lds;
+    Counters cnt{};
+    const uint32_t lds_base_floats = (spectral_rows + L.stack_lds) * BLOCK;
+    const SceneView view = stage_scene<false>(S0, lds, lds_base_floats, true);
+    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
+    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_TABLES ? S0.lds_table_floats : 0));
+    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
+    // slot field f of logic lane i: row f, column i of the stack rows; the count of finished logic waves: a word no lane owns
+    lds_u32* slots = (lds_u32*)reinterpret_cast<uint32_t*>(stack_rows);
+    lds_u32* logic_done = (lds_u32*)reinterpret_cast<uint32_t*>(lds + (SS + 1) * BLOCK + kSplitLogicLanes);
+    if (threadIdx.x < kSplitLogicLanes) slots[threadIdx.x] = SLOT_EMPTY;
+    if (threadIdx.x == 0) *logic_done = 0u;
+    __syncthreads();
+
+    if (wave < kSplitLogicWaves) {
+        // ------------------------------------------------------------------ logic waves: the paths
+        const uint32_t me = threadIdx.x;
+        const uint32_t total_logic_waves = gridDim.x * kSplitLogicWaves;
+        const int quorum = (int)L.sm_phase_lanes, expose_quorum = (int)L.sm_expose_lanes;
+        const float* wave_wl = lds + (threadIdx.x & ~63u);
+        float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+        Walker<COUNT, false, true> w;
+        w.chunk = L.chunk_begin + blockIdx.x * kSplitLogicWaves + wave;
+        w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
+        w.tape_column = blockIdx.x * BLOCK + threadIdx.x;
+        uint32_t empty_polls = 0;
+        PROF_DECL;
+        const unsigned long long prof_start = PROF_NOW();
+        unsigned long long prof_idle = 0;
+        for (;;) {
+            if (w.stage == ST_WAIT && slot_load(slots + me) == SLOT_DONE) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                w.t.closest = __uint_as_float(slots[1 * BLOCK + me]);
+                w.t.shape = slots[2 * BLOCK + me];
+                w.t.u = __uint_as_float(slots[3 * BLOCK + me]);
+                w.t.v = __uint_as_float(slots[4 * BLOCK + me]);
+                w.t.blocked = slots[5 * BLOCK + me] != 0u;
+                w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+            }
+            int nS = __builtin_popcountll(ballot64(w.stage == ST_SHADE));
+            int nN = __builtin_popcountll(ballot64(w.stage == ST_NEE));
+            int nE = __builtin_popcountll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+            const int nW = __builtin_popcountll(ballot64(w.stage == ST_WAIT));
+            if (nS + nN + nE + nW == 0) break; // every lane is DONE
+            // with rays out it pays to wait for a fuller phase (waiting costs no issue slots) -- but not for ever
+            const bool patient = nW > 0 && empty_polls < (uint32_t)PYR_SPLIT_PATIENCE;
+            bool ran = false;
+            if (nE > 0 && (nE >= expose_quorum || (!patient && nE == max(max(nS, nN), nE)))) {
+                PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
+                replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+                w.expose_and_restart(S, L, spec, cnt, lane, total_logic_waves);
+                PROF_END(0);
+                ran = true;
+                nS = __builtin_popcountll(ballot64(w.stage == ST_SHADE));
+                nE = 0;
+            }
+            if (nS > 0 && (nS >= quorum || (!patient && nS == max(max(nS, nN), nE)))) {
+                PROF_BEGIN(1, w.stage == ST_SHADE);
+                w.shade(S, L, spec, cnt);
+                PROF_END(1);
+                ran = true;
+                nN = __builtin_popcountll(ballot64(w.stage == ST_NEE));
+                nE = __builtin_popcountll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+                nS = 0;
+            }
+            if (nN > 0 && (nN >= quorum || (!patient && nN == max(max(nS, nN), nE)))) {
+                PROF_BEGIN(2, w.stage == ST_NEE);
+                w.next_event(S, L, spec, cnt);
+                PROF_END(2);
+                ran = true;
+            }
+            if (w.stage == ST_TRAV) { // a new ray: post it
+                slots[1 * BLOCK + me] = __float_as_uint(w.t.o.x), slots[2 * BLOCK + me] = __float_as_uint(w.t.o.y), slots[3 * BLOCK + me] = __float_as_uint(w.t.o.z);
+                slots[4 * BLOCK + me] = __float_as_uint(w.t.d.x), slots[5 * BLOCK + me] = __float_as_uint(w.t.d.y), slots[6 * BLOCK + me] = __float_as_uint(w.t.d.z);
+                slots[7 * BLOCK + me] = __float_as_uint(w.t.limit);
+                slots[8 * BLOCK + me] = __float_as_uint(w.t.closest);
+                slots[9 * BLOCK + me] = w.t.shape;
+                slots[10 * BLOCK + me] = w.t.shadow ? 1u : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                slot_store(slots + me, SLOT_REQUESTED);
+                w.stage = ST_WAIT;
+            }
+            if (ran) {
+                empty_polls = 0;
+            } else {
+                const unsigned long long prof_t = PROF_NOW();
+                __builtin_amdgcn_s_sleep(PYR_SPLIT_SLEEP);
+                prof_idle += PROF_NOW() - prof_t;
+                if (++empty_polls > kSplitSpinLimit) { // the traversal waves are gone: fail loudly, do not hang the GPU
+                    *L.tape_overflow = 2u;
+                    break;
+                }
+            }
+        }
+        PROF_EXTRA(12, prof_idle);
+        PROF_EXTRA(14, PROF_NOW() - prof_start);
+        PROF_FLUSH();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(logic_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        // ------------------------------------------------------------------ traversal waves: the rays
+        const int trav_steps = (int)L.sm_trav_steps;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        Trav t{};
+        t.node = 0, t.sp = 0;
+        bool busy = false;
+        uint32_t slot = 0, empty_polls = 0;
+        PROF_DECL;
+        const unsigned long long prof_start = PROF_NOW();
+        unsigned long long prof_idle = 0;
+        for (;;) {
+            const unsigned long long busy_mask = ballot64(busy);
+            int n_idle = 64 - __builtin_popcountll(busy_mask);
+            if (n_idle >= PYR_SPLIT_REFILL) {
+                // claim posted rays, at most one per idle lane: 64 slots at a time, the two traversal waves from opposite ends
+                uint32_t claimed = 0;
+                for (uint32_t part = 0; part < kSplitLogicWaves; ++part) {
+                    const uint32_t candidate = ((part + wave) % kSplitLogicWaves) * 64u + lane;
+                    const bool posted = slot_load(slots + candidate) == SLOT_REQUESTED;
+                    const unsigned long long posted_mask = ballot64(posted);
+                    bool mine = false;
+                    if (posted && __builtin_popcountll(posted_mask & below) < n_idle) {
+                        uint32_t expected = SLOT_REQUESTED; // the other traversal wave may have been faster
+                        mine = __hip_atomic_compare_exchange_strong(slots + candidate, &expected, SLOT_TAKEN, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    const unsigned long long mine_mask = ballot64(mine);
+                    if (mine) wave_list[claimed + __builtin_popcountll(mine_mask & below)] = candidate;
+                    const int got = __builtin_popcountll(mine_mask);
+                    claimed += (uint32_t)got;
+                    n_idle -= got;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rank = (uint32_t)__builtin_popcountll(~busy_mask & below);
+                if (!busy && rank < claimed) {
+                    slot = wave_list[rank];
+                    t.o = mk(__uint_as_float(slots[1 * BLOCK + slot]), __uint_as_float(slots[2 * BLOCK + slot]), __uint_as_float(slots[3 * BLOCK + slot]));
+                    t.d = mk(__uint_as_float(slots[4 * BLOCK + slot]), __uint_as_float(slots[5 * BLOCK + slot]), __uint_as_float(slots[6 * BLOCK + slot]));
+                    t.limit = __uint_as_float(slots[7 * BLOCK + slot]);
+                    t.closest = __uint_as_float(slots[8 * BLOCK + slot]);
+                    t.shape = slots[9 * BLOCK + slot];
+                    t.shadow = slots[10 * BLOCK + slot] != 0u;
+                    t.u = t.v = 0.0f;
+                    trav_restart(t);
+                    t.inv = box_reciprocal(t.d);
+                    busy = true;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ballot64(busy) == 0ull) {
+                if (slot_load(logic_done) == kSplitLogicWaves) break; // every path of this workgroup is finished
+                const unsigned long long prof_t = PROF_NOW();
+                __builtin_amdgcn_s_sleep(PYR_SPLIT_SLEEP);
+                prof_idle += PROF_NOW() - prof_t;
+                if (++empty_polls > kSplitSpinLimit) {
+                    *L.tape_overflow = 2u;
+                    break;
+                }
+                continue;
+            }
+            empty_polls = 0;
+#ifdef PYR_PHASE_PROFILE
+            const unsigned long long prof_t0_3 = clock64();
+#endif
+            for (int step = 0; step < trav_steps; ++step) {
+                PROF_LANES(3, busy);
+                if (trav_step_lean<COUNT>(view, t, stack, cnt, busy)) {
+                    slots[1 * BLOCK + slot] = __float_as_uint(t.closest);
+                    slots[2 * BLOCK + slot] = t.shape;
+                    slots[3 * BLOCK + slot] = __float_as_uint(t.u);
+                    slots[4 * BLOCK + slot] = __float_as_uint(t.v);
+                    slots[5 * BLOCK + slot] = t.blocked ? 1u : 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    slot_store(slots + slot, SLOT_DONE);
+                    busy = false;
+                }
+            }
+            PROF_END(3);
+        }
+        PROF_EXTRA(13, prof_idle);
+        PROF_EXTRA(15, PROF_NOW() - prof_start);
+        PROF_FLUSH();
+    }
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -3449,7 +3705,7 @@ uint32_t tape_ops_bound(const RenderLaunch& launch) { return 2u * launch.bounces
 uint32_t tape_lanes_bound(int num_cus) { return (uint32_t)num_cus * 8u * BLOCK; } // launch_render never starts more than 8 blocks per CU
 constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for the replay (4 KB); scenes with more use the HBM records
 static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_programs <= kTapeProgramsLds ? scene.num_programs : 0u; }
-static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return launch.scheduler == 1 && scene.needs_interpreter == 0; }
+static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return (launch.scheduler == 1 || launch.scheduler == 3) && scene.needs_interpreter == 0; }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
     size_t bytes = (spectral_rows + launch.stack_lds) * BLOCK * sizeof(float);
@@ -3484,8 +3740,12 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     RenderLaunch launch = launch_in;
     launch.stack_lds = 0;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
-    // the stage-scheduled kernel is built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
-    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), PYR_SM_WAVES) : scene.stack_depth;
+    // the stage-scheduled kernels are built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
+    launch.stack_lds = launch.scheduler == 1 || launch.scheduler == 3 ? short_stack_levels(scene, render_lds_bytes(scene, launch), PYR_SM_WAVES) : scene.stack_depth;
+    // the split scheduler walks four-child trees with triangle pairs only, keeps its slots in the stack rows and has no
+    // interpreter form: anything else runs on the stage scheduler
+    if (launch.scheduler == 3 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene) || launch.stack_lds < kSplitRows))
+        launch.scheduler = 1;
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
@@ -3494,6 +3754,11 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
     RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0);
+    if (launch.scheduler == 3) {
+        static const RenderKernel split_variants[2][2] = {{render_kernel_split<false, false>, render_kernel_split<false, true>},
+                                                          {render_kernel_split<true, false>, render_kernel_split<true, true>}};
+        kernel = split_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0];
+    }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
@@ -3510,7 +3775,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     }
     blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
-    uint32_t blocks_needed = (chunks + (BLOCK / 64) - 1) / (BLOCK / 64);
+    const uint32_t path_waves = launch.scheduler == 3 ? kSplitLogicWaves : BLOCK / 64; // waves of a workgroup that take chunks
+    uint32_t blocks_needed = (chunks + path_waves - 1) / path_waves;
     if (grid > blocks_needed) grid = blocks_needed;
     if (uses_tape(scene, launch) && (launch.tape == nullptr || (size_t)grid * BLOCK > launch.tape_lanes || launch.tape_max_ops < tape_ops_bound(launch))) {
         g_kernel_error = "the spectral tape is missing or too small for this launch";

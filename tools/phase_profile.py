@@ -50,3 +50,6 @@ for i, name in enumerate(["EXPOSE/NEW", "SHADE", "NEE", "TRAV"]):
     per_turn = cyc[i] / (n / (int(os.environ.get("PYRITE_SM_STEPS", "8")) if i == 3 else 1))
     print("%-11s %5.1f %% of wave cycles | mean active lanes %5.1f / 64 | %8.0f cycles per turn | %.2f turns per sample"
           % (name, 100.0 * cyc[i] / total, lanes[i] / n, per_turn, turns[i] * 64.0 / samples / (8 if i == 3 else 1)))
+if any(out[12:16]):  # render_kernel_split: waves in two roles
+    print("split scheduler: logic waves idle %.1f %% of their cycles, traversal waves idle %.1f %%" % (100.0 * out[12] / max(out[14], 1), 100.0 * out[13] / max(out[15], 1)))
+    print("                 wave cycles logic %.3g, traversal %.3g" % (out[14], out[15]))
