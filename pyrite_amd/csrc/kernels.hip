@@ -1246,14 +1246,18 @@ DEV SceneView stage_scene(const DevScene& S, float* lds, uint32_t lds_floats_bef
 // -1: decided at run time from S.lds_table_floats). With a run-time choice the pointers are generic and every table access
 // is a flat_load that must drain both vmcnt and lgkmcnt (MI355X_MICROARCH.md: flat completes out of order); with a
 // compile-time one they are global_load / s_load or ds_read.
-template <int TABLES>
+// COPY = false only rebuilds the record that points at the staged copies (a dozen scalar operations): the stage-scheduled
+// kernel does that at the head of every phase from the kernel-argument segment (scene_from_kernarg) rather than keep the
+// record's ~40 uniform words alive -- and spilled to VGPR lanes -- across the whole stage loop.
+template <int TABLES, bool COPY = true>
 DEV DevScene stage_tables(const DevScene& S, float* lds, uint32_t lds_floats_before) {
     DevScene local = S;
     if (TABLES == 1 || (TABLES == -1 && S.lds_table_floats != 0)) {
         float* dst = lds + lds_floats_before;
         auto stage = [&](const void* src, uint32_t floats) {
             const float* from = reinterpret_cast<const float*>(src);
-            for (uint32_t i = threadIdx.x; i < floats; i += BLOCK) dst[i] = from[i];
+            if (COPY)
+                for (uint32_t i = threadIdx.x; i < floats; i += BLOCK) dst[i] = from[i];
             float* at = dst;
             dst += floats;
             return at;
@@ -1272,7 +1276,7 @@ DEV DevScene stage_tables(const DevScene& S, float* lds, uint32_t lds_floats_bef
         local.programs = reinterpret_cast<const DevProgram*>(stage(S.programs, S.num_programs * (uint32_t)(sizeof(DevProgram) / sizeof(float))));
         local.lamps = reinterpret_cast<const DevLamp*>(stage(S.lamps, S.num_lamps * (uint32_t)(sizeof(DevLamp) / sizeof(float))));
 #endif
-        __syncthreads();
+        if (COPY) __syncthreads();
     }
     return local;
 }
@@ -1582,6 +1586,30 @@ DEV void finish_path(const RenderLaunch& L, const Path& p, Spectral& spec, Count
 //   * refilling a lane as soon as its path ends (one bounce per loop turn)                         0.60x
 //   * parking survivors of the first two bounces in a ballot-compacted HBM queue for a tail kernel  0.93x
 // (MI355X, C2, 64 spp; both were built and measured, see DESIGN.md "Scheduling experiments").
+// The launch record as the kernel-argument segment holds it, behind a pointer the compiler cannot see through. The stage
+// loop keeps ~100 uniform scene / launch values alive; there are 104 scalar registers, so the allocator parks the rest in
+// lanes of a VGPR and fetches them back with v_readlane -- vector instructions, sixteen in a row where a phase wants the
+// camera -- in a kernel that is bound by vector issue. Read through this reference at the head of a phase the fields are
+// s_load'ed from the (scalar-cached) argument segment where they are used and die with the phase.
+#ifndef PYR_RELOAD_LAUNCH
+#define PYR_RELOAD_LAUNCH 1
+#endif
+typedef __attribute__((address_space(4))) const RenderLaunch* kernarg_launch_ptr;
+constexpr size_t kLaunchKernargOffset = (sizeof(DevScene) + alignof(RenderLaunch) - 1) / alignof(RenderLaunch) * alignof(RenderLaunch);
+typedef __attribute__((address_space(4))) const DevScene* kernarg_scene_ptr;
+DEV const DevScene& scene_from_kernarg(const DevScene& by_value) { // the scene record: the first kernel argument
+    if (!PYR_RELOAD_LAUNCH) return by_value;
+    unsigned long long at = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(at));
+    return *(const DevScene*)(kernarg_scene_ptr)at;
+}
+DEV const RenderLaunch& launch_from_kernarg(const RenderLaunch& by_value) {
+    if (!PYR_RELOAD_LAUNCH) return by_value;
+    unsigned long long at = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + kLaunchKernargOffset;
+    asm volatile("" : "+s"(at));
+    return *(const RenderLaunch*)(kernarg_launch_ptr)at;
+}
+
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
@@ -1608,16 +1636,16 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
         TileArea area;
         if (!locate_chunk(L, chunk, lane, tile, iteration, area)) continue;
         Path p{};
-        start_sample(L, tile, iteration, area, p, spec);
+        start_sample(launch_from_kernarg(L), tile, iteration, area, p, spec);
         if (COUNT) cnt.samples++;
         SLAP(sp, 0);
         while (p.bounce < L.bounces) {
-            const bool ended = bounce_step<COUNT, INTERP>(S, L, view, p, spec, stack, cnt, sp);
+            const bool ended = bounce_step<COUNT, INTERP>(S, launch_from_kernarg(L), view, p, spec, stack, cnt, sp);
             p.bounce++;
             if (ended) break;
         }
         SLAP(sp, 6);
-        finish_path<COUNT>(L, p, spec, cnt);
+        finish_path<COUNT>(launch_from_kernarg(L), p, spec, cnt);
         SLAP(sp, 7);
     }
 #ifdef PYR_PHASE_PROFILE
@@ -2691,23 +2719,6 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
     return n_spectral > kTapeEagerSlots ? 0u : n_spectral; // too many for the reserved rows: the replay looks them up record by record
 }
 
-// The launch record as the kernel-argument segment holds it, behind a pointer the compiler cannot see through. The stage
-// loop keeps ~100 uniform scene / launch values alive; there are 104 scalar registers, so the allocator parks the rest in
-// lanes of a VGPR and fetches them back with v_readlane -- vector instructions, sixteen in a row where a phase wants the
-// camera -- in a kernel that is bound by vector issue. Read through this reference at the head of a phase the fields are
-// s_load'ed from the (scalar-cached) argument segment where they are used and die with the phase.
-#ifndef PYR_RELOAD_LAUNCH
-#define PYR_RELOAD_LAUNCH 1
-#endif
-typedef __attribute__((address_space(4))) const RenderLaunch* kernarg_launch_ptr;
-constexpr size_t kLaunchKernargOffset = (sizeof(DevScene) + alignof(RenderLaunch) - 1) / alignof(RenderLaunch) * alignof(RenderLaunch);
-DEV const RenderLaunch& launch_from_kernarg(const RenderLaunch& by_value) {
-    if (!PYR_RELOAD_LAUNCH) return by_value;
-    unsigned long long at = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + kLaunchKernargOffset;
-    asm volatile("" : "+s"(at));
-    return *(const RenderLaunch*)(kernarg_launch_ptr)at;
-}
-
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
 __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
@@ -2745,6 +2756,12 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         w.tape_column = blockIdx.x * BLOCK + threadIdx.x;
     }
 
+    // the scene record as the phases see it (table pointers at the staged copies), rebuilt where a phase starts
+    auto scene_view = [&](const RenderLaunch& Lp) {
+        if (!PYR_RELOAD_LAUNCH || LDS_SCENE) return S;
+        const uint32_t rows = (TAPE ? Lp.spectrum_samples + 1 + kTapeEagerSlots : 3 * Lp.spectrum_samples) + Lp.stack_lds;
+        return stage_tables<LDS_TABLES ? 1 : 0, false>(scene_from_kernarg(S0), lds, rows * BLOCK);
+    };
     PROF_DECL;
     for (;;) {
         // every decision looks at the lanes as they are now: a lane that has just been shaded and starts its next-event
@@ -2758,8 +2775,9 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         if (nE >= expose_lanes || nE == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             const RenderLaunch& Lp = launch_from_kernarg(L);
-            if constexpr (TAPE) replay_tapes<COUNT>(S, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
-            w.expose_and_restart(S, Lp, spec, cnt, lane, total_waves);
+            const DevScene Sp = scene_view(Lp);
+            if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+            w.expose_and_restart(Sp, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
             nS = __popcll(__ballot(w.stage == ST_SHADE));
@@ -2767,7 +2785,8 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         }
         if (nS >= phase_lanes || nS == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(1, w.stage == ST_SHADE);
-            w.shade(S, launch_from_kernarg(L), spec, cnt);
+            const RenderLaunch& Lp = launch_from_kernarg(L);
+            w.shade(scene_view(Lp), Lp, spec, cnt);
             PROF_END(1);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
             nN = __popcll(__ballot(w.stage == ST_NEE));
@@ -2776,7 +2795,8 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
         }
         if (nN >= phase_lanes || nN == max(max(nT, nS), max(nN, nE))) {
             PROF_BEGIN(2, w.stage == ST_NEE);
-            w.next_event(S, launch_from_kernarg(L), spec, cnt);
+            const RenderLaunch& Lp = launch_from_kernarg(L);
+            w.next_event(scene_view(Lp), Lp, spec, cnt);
             PROF_END(2);
             nT = __popcll(__ballot(w.stage == ST_TRAV));
             nN = __popcll(__ballot(w.stage == ST_NEE));
