@@ -23,6 +23,13 @@ FLAGS = [
     # registers and the ray origin / direction live in scratch for the whole render (24 B per lane stored at every new ray,
     # read back at every traversal entry and hit). Without the pass: no such alloca, C3 352 -> 363 Msamples/s at 32 spp.
     "-mllvm", "-disable-vector-combine",
+    # The SLP vectorizer pairs scalar f32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32 wherever two happen to be
+    # independent -- and pays for each pair with v_mov's that bring the operands into consecutive registers, plus the
+    # register pressure of the tuples: in kernels bound by vector issue that is a loss everywhere. The packed arithmetic that
+    # pays (box tests, triangle pairs) is written with ext_vector types and stays. Without the pass: no VGPR spills left in
+    # the stage-scheduled kernel (388 -> 268 B of scratch = the traversal stack's deep end), intersect_kernel 84 -> 78 VGPRs
+    # (5 -> 6 waves per SIMD); C3 396 -> 426, C5 350 -> 375, C2 745 -> 772 Msamples/s, World::intersect 8.07 -> 8.50 Grays/s.
+    "-fno-slp-vectorize",
 ]
 
 
