@@ -266,8 +266,10 @@ WideBvh collapse_to_wide(const BuiltBvh& bvh) {
             if (c.code >= 0 || ((uint32_t)(-1 - c.code) & 7u) != 0) real.push_back(c);
         Node128 node{};
         for (int k = 0; k < 4; ++k) {
-            node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = kInf;
-            node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = -kInf;
+            // an unused slot's box is NaN: every comparison of the slab test fails on it, so the traversal needs no "is there a
+            // child" test of its own (an inverted box would not do: the slab test orders each pair of planes itself)
+            node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = std::numeric_limits<float>::quiet_NaN();
+            node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = std::numeric_limits<float>::quiet_NaN();
             node.child[k] = kEmptyChild;
         }
         const uint32_t pushes = real.empty() ? 0u : (uint32_t)real.size() - 1u;

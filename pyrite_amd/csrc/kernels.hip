@@ -1801,9 +1801,9 @@ DEV void wide_node_children(const float4 lx, const float4 ly, const float4 lz, c
             const float tmin = fmaxf(fmaxf(fminf(tl[k][0], th[k][0]), fminf(tl[k][1], th[k][1])), fminf(tl[k][2], th[k][2]));
             const float tmax = fminf(fminf(fmaxf(tl[k][0], th[k][0]), fmaxf(tl[k][1], th[k][1])), fmaxf(tl[k][2], th[k][2]));
             const float entry = fmaxf(tmin, 0.0f);
-            const bool present = c[k] != INT32_MIN;
-            if (COUNT) cnt.box_tests += present ? 1u : 0u;
-            const bool hit = (tmax >= tmin) & (tmax >= 0.0f) & present & (entry < t.closest);
+            if (COUNT) cnt.box_tests += c[k] != INT32_MIN ? 1u : 0u;
+            // tmax >= max(tmin, 0) is (tmax >= tmin) & (tmax >= 0); an unused slot's box is NaN (bvh.cpp) and fails it
+            const bool hit = (tmax >= entry) & (entry < t.closest);
             e[k] = hit ? entry : PYR_INF; // misses sort last
             c[k] = hit ? c[k] : INT32_MIN;
         }

@@ -268,6 +268,33 @@ def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
         assert gcount["exposures"] < gcount["samples"] * 10  # dispersed paths expose the hero wavelength only
 
 
+@pytest.mark.parametrize("glass", [False, True])
+def test_split_scheduler_on_a_c3_shaped_scene(glass, gpu_lib, monkeypatch):
+    """render_kernel_split (logic waves own the paths, traversal waves walk the tree, rays handed over in LDS slots) on the
+    C3 / C5-shaped scene: the oracle's film and path counters, ragged tiles, with and without the counters build. The scene
+    is big enough for the four-child tree with triangle pairs the scheduler requires (smaller ones run on the stage scheduler)."""
+    from pyrite_amd.renderer import Camera, Renderer, World
+
+    monkeypatch.setenv("PYRITE_SCHEDULER", "split")
+    project = scenes.c3_mesh_in_box(width=50, height=30, pixel_samples=5, glass=glass, bounces=20 if glass else None)
+    world = World(scenes.c3_flat(segments=96, sides=48, glass=glass))
+    r = Renderer.from_project(project["renderer"], seed=13)
+    cam = Camera.from_project(project["camera"])
+    gfilm, plain, cfilm = r.new_film(50, 30), r.new_film(50, 30), r.new_film(50, 30)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    gcount = r.render(gfilm, cam, world, counters=True)
+    r.render(plain, cam, world)
+    assert_parity(gfilm, cfilm)
+    assert_parity(plain, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+    monkeypatch.setenv("PYRITE_SCHEDULER", "sm")
+    sm_film = r.new_film(50, 30)
+    scount = r.render(sm_film, cam, world, counters=True)
+    assert scount == gcount  # the same steps, box for box: the traversal is the stage scheduler's
+    assert_parity(sm_film, gfilm)
+
+
 @pytest.mark.parametrize("slots", ["64", "640", ""])
 @pytest.mark.parametrize("glass", [False, True])
 def test_wavefront_scheduler_on_a_c3_shaped_scene(glass, slots, gpu_lib, monkeypatch):
