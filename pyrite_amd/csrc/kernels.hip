@@ -2215,7 +2215,14 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
 // quotes the numbers): -DPYR_TAPE_NOSTORE (no records written), -DPYR_TAPE_NOREPLAY (no replay), -DPYR_REPLAY_NOEVAL (record
 // by record path: programs evaluate to 1), -DPYR_REPLAY_NOEXPOSE (no film atomics).
 constexpr uint32_t kTapeEagerSlots = 8; // LDS rows for the values of the programs that read a spectrum (replay_tapes)
-constexpr uint32_t TAPE_MUL = 0u, TAPE_ADD = 1u, TAPE_SCALE = 2u, TAPE_HERO_ONLY = 1u << 29, TAPE_CONSTANT = 1u << 28, TAPE_PROGRAM_MASK = (1u << 28) - 1u;
+constexpr uint32_t TAPE_MUL = 0u, TAPE_ADD = 1u, TAPE_SCALE = 2u, TAPE_HERO_ONLY = 1u << 29, TAPE_PROGRAM_MASK = (1u << 28) - 1u;
+// Records of the eager replay (the scene's spectrum-reading programs fit the LDS value rows): every record is "m = value[slot] * s;
+// then reflectance *= m, or brightness += m * reflectance" -- bit 31 says which, bits 8-11 the slot (as an index into the value
+// rows: slot * BLOCK). A constant program's value was folded into s when the record was written, and the BRDF factor is a
+// plain factor: both name the slot that holds 1.0 (x * 1.0 is x, bit for bit), so the replay has one straight-line form.
+constexpr uint32_t TAPE_EAGER_ADD = 1u << 31, TAPE_EAGER_SLOT_SHIFT = 8, TAPE_EAGER_SLOT_MASK = 0xFu << TAPE_EAGER_SLOT_SHIFT;
+constexpr uint32_t kTapeOneSlot = kTapeEagerSlots - 1; // the value row that holds 1.0
+static_assert(BLOCK == 1u << TAPE_EAGER_SLOT_SHIFT, "an eager record's slot field is an index into rows of BLOCK floats");
 
 template <bool COUNT, bool INTERP, bool TAPE = false>
 struct Walker {
@@ -2231,16 +2238,18 @@ struct Walker {
 #endif
         {
             uint32_t word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | (program & TAPE_PROGRAM_MASK);
-            if (tape_prepared != nullptr && kind != TAPE_SCALE) {
+            if (tape_prepared != nullptr) {
                 // eager replay: the record names the LDS slot of the program's value; a constant program is folded into the
                 // factor -- c * s is the very product `contribute` forms (program value times probability)
-                const uint32_t* e = tape_prepared + 8 * program;
-                if (e[0] == 0u) {
-                    word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | TAPE_CONSTANT;
-                    s = __uint_as_float(e[1]) * s;
-                } else {
-                    word = (kind << 30) | (hero_only ? TAPE_HERO_ONLY : 0u) | e[7];
+                uint32_t slot = kTapeOneSlot;
+                if (kind != TAPE_SCALE) {
+                    const uint32_t* e = tape_prepared + 8 * program;
+                    if (e[0] == 0u)
+                        s = __uint_as_float(e[1]) * s;
+                    else
+                        slot = e[7];
                 }
+                word = (kind == TAPE_ADD ? TAPE_EAGER_ADD : 0u) | (hero_only ? TAPE_HERO_ONLY : 0u) | (slot << TAPE_EAGER_SLOT_SHIFT);
             }
             L.tape[(size_t)n_ops * L.tape_lanes + tape_column] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
         }
@@ -2623,25 +2632,19 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 words[j] = (uint32_t)__shfl((int)(uint32_t)rows[j], (int)src);
                 factors[j] = __uint_as_float((uint32_t)__shfl((int)(uint32_t)(rows[j] >> 32), (int)src));
             }
-            if (eager) { // the factor is s itself (constant program, folded when recorded) or the slot's value times s
-                float vs[ROWS];
+            if (eager) { // straight-line: m = value[slot] * s, then one of the two updates, chosen by selects
+                float values[ROWS];
+#pragma unroll
+                for (uint32_t j = 0; j < ROWS; ++j) values[j] = spectral_values[words[j] & TAPE_EAGER_SLOT_MASK]; // slot << 8 is slot * BLOCK
+                const uint32_t not_for_me = hero ? 0u : TAPE_HERO_ONLY; // a hero-only record is skipped by the companions
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) {
-                    const uint32_t slot = words[j] & (kTapeEagerSlots - 1u); // SCALE records carry slot 0: a harmless read
-                    vs[j] = (words[j] & TAPE_CONSTANT) ? factors[j] : spectral_values[slot * BLOCK] * factors[j];
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < ROWS; ++j) {
-                    if (!run || r0 + j >= ops) continue;
-                    const uint32_t kind = words[j] >> 30;
-                    if (kind == TAPE_SCALE)
-                        refl *= factors[j];
-                    else if (!(words[j] & TAPE_HERO_ONLY) || hero) {
-                        if (kind == TAPE_MUL)
-                            refl *= vs[j];
-                        else
-                            bright += vs[j] * refl;
-                    }
+                    const float m = values[j] * factors[j];
+                    const bool apply = run & (r0 + j < ops) & ((words[j] & not_for_me) == 0u);
+                    const bool adds = (int)words[j] < 0;
+                    const float multiplied = refl * m, added = bright + m * refl;
+                    bright = (apply & adds) ? added : bright;
+                    refl = (apply & !adds) ? multiplied : refl;
                 }
                 continue;
             }
@@ -2713,10 +2716,10 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
         uint32_t* e = prepared_lds + 8 * i;
         e[0] = q.mode, e[1] = __float_as_uint(q.c), e[2] = q.sp.format, e[3] = __float_as_uint(q.sp.min), e[4] = __float_as_uint(q.sp.max);
         e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = slot;
-        if (reads_spectrum(i) && slot < kTapeEagerSlots) prepared_lds[8 * L.tape_programs_lds + slot] = i;
+        if (reads_spectrum(i) && slot < kTapeOneSlot) prepared_lds[8 * L.tape_programs_lds + slot] = i;
     }
     __syncthreads();
-    return n_spectral > kTapeEagerSlots ? 0u : n_spectral; // too many for the reserved rows: the replay looks them up record by record
+    return n_spectral > kTapeOneSlot ? 0u : n_spectral; // too many for the reserved rows (the last one holds 1.0): the replay looks them up record by record
 }
 
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
@@ -2750,6 +2753,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
     // programs that read a spectrum get a slot (their rank among such programs); the slot -> program list follows the table
     uint32_t n_spectral = 0;
     float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+    spectral_values[kTapeOneSlot * BLOCK] = 1.0f; // eager records of constant programs and BRDF factors (tape_push)
     if constexpr (TAPE) {
         n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
         if (n_spectral != 0) w.tape_prepared = prepared_lds;
@@ -2895,6 +2899,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_split(DevSc
         const int quorum = (int)L.sm_phase_lanes, expose_quorum = (int)L.sm_expose_lanes;
         const float* wave_wl = lds + (threadIdx.x & ~63u);
         float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+        spectral_values[kTapeOneSlot * BLOCK] = 1.0f; // eager records of constant programs and BRDF factors (tape_push)
         Walker<COUNT, false, true> w;
         w.chunk = L.chunk_begin + blockIdx.x * kSplitLogicWaves + wave;
         w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
@@ -3417,6 +3422,7 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_tape_kernel(DevScene S0, Re
     const float* wave_wl = lds + (threadIdx.x & ~63u);
     uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
     float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+    spectral_values[kTapeOneSlot * BLOCK] = 1.0f; // eager records of constant programs and BRDF factors (tape_push)
     if (blockIdx.x == 0 && threadIdx.x < kFeedSegments) P.next[threadIdx.x * kFeedCursorStride] = 0; // the traversal kernel that follows starts afresh
     // threads take the workgroup's slots sorted by entry stage (see wf_logic_kernel)
     __shared__ uint32_t wave_counts[BLOCK / 64][4];
