@@ -1730,7 +1730,7 @@ DEV bool trav_begin(const DevScene& S, Trav& t, f3 o, f3 d, bool shadow, float l
     t.d = d;
     t.shadow = shadow;
     t.blocked = false;
-    t.limit = limit;
+    t.limit = shadow ? limit : -PYR_INF; // an extension ray is blocked by nothing: `dist * dist < t.limit` never holds, and the leaf tests need no ray kind
     t.closest = PYR_INF;
     t.shape = PYR_HIT_NONE;
     t.u = t.v = 0.0f;
@@ -1882,8 +1882,11 @@ DEV bool leaf_prim_test(const float4 a, const float4 b, const float4 c, Trav& t,
     }
     // the verdict as selects (world.rs:290 for an extension ray, tracer.rs:381-389 for a shadow ray), then where to go next
     ok = ok & (dist > DIST_EPSILON);
-    const bool blocks = ok & t.shadow & (dist * dist < t.limit);
-    const bool closer = ok & !t.shadow & (dist < t.closest);
+    // No ray kind in here: an extension ray's limit is -inf (trav_begin). A shadow ray may take a hit as its `closest` too --
+    // one in the 0.1 % margin beyond the limit, nearer than the cut-off: every blocker is nearer still (its distance squared is
+    // below the limit), so its boxes stay inside the tighter cut-off; the hit itself is read by nobody.
+    const bool blocks = ok & (dist * dist < t.limit);
+    const bool closer = ok & (dist < t.closest);
     t.blocked = t.blocked | blocks;
     t.closest = closer ? dist : t.closest;
     t.shape = closer ? shape : t.shape;
@@ -2001,10 +2004,10 @@ DEV bool leaf_pair_test(const float4 q0, const float4 q1, const float4 q2, const
         return !(det_ > -DIST_EPSILON && det_ < DIST_EPSILON) & !(u_ < 0.0f || u_ > 1.0f) & !(v_ < 0.0f || u_ + v_ > 1.0f) & (dist_ > DIST_EPSILON);
     };
     const bool ok_a = passes(det.x, u.x, v.x, dist.x), ok_b = passes(det.y, u.y, v.y, dist.y) & (count >= 2u);
-    const bool blocks = t.shadow & ((ok_a & (dist.x * dist.x < t.limit)) | (ok_b & (dist.y * dist.y < t.limit)));
-    const bool closer_a = ok_a & !t.shadow & (dist.x < t.closest);
+    const bool blocks = (ok_a & (dist.x * dist.x < t.limit)) | (ok_b & (dist.y * dist.y < t.limit)); // see leaf_prim_test: no ray kind
+    const bool closer_a = ok_a & (dist.x < t.closest);
     const float after_a = closer_a ? dist.x : t.closest;
-    const bool closer_b = ok_b & !t.shadow & (dist.y < after_a);
+    const bool closer_b = ok_b & (dist.y < after_a);
     t.blocked = t.blocked | blocks;
     t.closest = closer_b ? dist.y : after_a;
     t.shape = closer_b ? shape_b : (closer_a ? shape_a : t.shape);
