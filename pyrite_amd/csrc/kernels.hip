@@ -34,6 +34,9 @@ thread_local std::string g_kernel_error;
 const char* kernels_last_error() { return g_kernel_error.c_str(); }
 
 #define DEV __device__ __forceinline__
+// The lanes for which p holds, as the mask the comparison produced (HIP's __ballot() goes through an integer and back: a
+// v_cndmask and a v_cmp per call).
+DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 constexpr int BLOCK = 256;
 #ifndef PYR_SM_WAVES
@@ -1672,9 +1675,9 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
 // Developer build only (-DPYR_PHASE_PROFILE, tools/phase_profile.py): per-phase wave cycles / active lanes / turns.
 #ifdef PYR_PHASE_PROFILE
 #define PROF_DECL unsigned long long prof_c[4] = {0, 0, 0, 0}, prof_l[4] = {0, 0, 0, 0}, prof_n[4] = {0, 0, 0, 0}
-#define PROF_BEGIN(ph, cond) const unsigned long long prof_t0_##ph = clock64(); prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
+#define PROF_BEGIN(ph, cond) const unsigned long long prof_t0_##ph = clock64(); prof_l[ph] += __popcll(ballot64(cond)); prof_n[ph]++
 #define PROF_END(ph) prof_c[ph] += clock64() - prof_t0_##ph
-#define PROF_LANES(ph, cond) prof_l[ph] += __popcll(__ballot(cond)); prof_n[ph]++
+#define PROF_LANES(ph, cond) prof_l[ph] += __popcll(ballot64(cond)); prof_n[ph]++
 #define PROF_NOW() clock64()
 #define PROF_EXTRA(idx, cycles) if ((threadIdx.x & 63u) == 0) atomicAdd(&g_phase_prof[idx], (unsigned long long)(cycles))
 #define PROF_FLUSH()                                                                                  \
@@ -2072,7 +2075,7 @@ DEV bool trav_step_postponed(const SceneView& view, Trav& t, TravStack& stack, C
         }
     }
     const bool want_node = active && t.node >= 0, want_leaf = active && t.parked != 0;
-    const int n_node = __popcll(__ballot(want_node)), n_leaf = __popcll(__ballot(want_leaf));
+    const int n_node = __popcll(ballot64(want_node)), n_leaf = __popcll(ballot64(want_leaf));
     if (n_leaf * 100 >= n_node * PYR_LEAF_WEIGHT) {
         if (want_leaf) {
             const uint32_t code = (uint32_t)(-1 - t.parked);
@@ -2116,7 +2119,6 @@ DEV bool trav_step_postponed(const SceneView& view, Trav& t, TravStack& stack, C
 //     hit is stored too -- at level sp + n, above the new top, where nothing lives;
 //   - node, stack pointer and the verdict are selects.
 // Same tests, same order of visits, same stack contents below the top as the generic step.
-DEV unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); } // the mask itself: __ballot() goes through an integer and back
 template <bool COUNT>
 DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active);
 // One step for the lanes of a wave that have a ray in flight (`active`), with a vote: a step is an inner-node visit or a
@@ -2144,7 +2146,7 @@ DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Count
     }
     if (PYR_UNIFIED_FETCH && view.wide && view.pairs == nullptr) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
     const bool at_node = t.node >= 0;
-    const unsigned long long nodes = __ballot(active && at_node), leaves = __ballot(active && !at_node);
+    const unsigned long long nodes = ballot64(active && at_node), leaves = ballot64(active && !at_node);
     if (PYR_VOTE_BOTH > 64) {
         // majority only: the choice is wave-uniform, so it is a scalar branch to ONE of the two bodies, not two masked regions
         if (__popcll(nodes) >= __popcll(leaves)) return (active && at_node) ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
@@ -2163,13 +2165,17 @@ template <bool COUNT>
 DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
     const bool at_node = t.node >= 0;
     const unsigned long long nodes = ballot64(active && at_node), leaves = ballot64(active && !at_node);
+    // the counts as 32-bit scalars the compiler cannot see through: left alone it compares the two 64-bit population counts,
+    // for which the scalar unit has no instruction -- two v_mov and a v_cmp_lt_u64 per step
+    int n_nodes = __builtin_popcountll(nodes), n_leaves = __builtin_popcountll(leaves);
+    asm volatile("" : "+s"(n_nodes), "+s"(n_leaves));
     if (ballot64(active && t.sp + 3 > stack.lds_entries) != 0ull) { // somebody's stack is about to leave LDS: the generic step
-        if (__builtin_popcountll(nodes) >= __builtin_popcountll(leaves)) return (active && at_node) ? trav_node_step<COUNT, true>(view, t, stack, cnt) : false;
+        if (n_nodes >= n_leaves) return (active && at_node) ? trav_node_step<COUNT, true>(view, t, stack, cnt) : false;
         return (active && !at_node) ? trav_leaf_step<COUNT, true>(view, t, stack, cnt) : false;
     }
     bool done = false;
     const int below = max(t.sp - 1, 0);
-    if (__builtin_popcountll(nodes) >= __builtin_popcountll(leaves)) {
+    if (n_nodes >= n_leaves) {
         if (active && at_node) {
             const int top = stack.lds[below * BLOCK];
             const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
@@ -2551,7 +2557,7 @@ template <bool COUNT>
 DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wave_wl,
                       uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long mask = __ballot(exposing);
+    const unsigned long long mask = ballot64(exposing);
     const uint32_t n = (uint32_t)__popcll(mask);
     if (n == 0) return;
 #ifdef PYR_TAPE_NOREPLAY
@@ -2773,10 +2779,10 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
     for (;;) {
         // every decision looks at the lanes as they are now: a lane that has just been shaded and starts its next-event
         // estimation is counted for the NEE phase of this same turn, one that has just drawn a shadow ray for the traversal
-        int nT = __popcll(__ballot(w.stage == ST_TRAV));
-        int nS = __popcll(__ballot(w.stage == ST_SHADE));
-        int nN = __popcll(__ballot(w.stage == ST_NEE));
-        int nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+        int nT = __popcll(ballot64(w.stage == ST_TRAV));
+        int nS = __popcll(ballot64(w.stage == ST_SHADE));
+        int nN = __popcll(ballot64(w.stage == ST_NEE));
+        int nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
         if (max(max(nT, nS), max(nN, nE)) == 0) break; // every lane is DONE
 
         if (nE >= expose_lanes || nE == max(max(nT, nS), max(nN, nE))) {
@@ -2786,8 +2792,8 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
             if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
             w.expose_and_restart(Sp, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
-            nT = __popcll(__ballot(w.stage == ST_TRAV));
-            nS = __popcll(__ballot(w.stage == ST_SHADE));
+            nT = __popcll(ballot64(w.stage == ST_TRAV));
+            nS = __popcll(ballot64(w.stage == ST_SHADE));
             nE = 0;
         }
         if (nS >= phase_lanes || nS == max(max(nT, nS), max(nN, nE))) {
@@ -2795,9 +2801,9 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
             const RenderLaunch& Lp = launch_from_kernarg(L);
             w.shade(scene_view(Lp), Lp, spec, cnt);
             PROF_END(1);
-            nT = __popcll(__ballot(w.stage == ST_TRAV));
-            nN = __popcll(__ballot(w.stage == ST_NEE));
-            nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+            nT = __popcll(ballot64(w.stage == ST_TRAV));
+            nN = __popcll(ballot64(w.stage == ST_NEE));
+            nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
             nS = 0;
         }
         if (nN >= phase_lanes || nN == max(max(nT, nS), max(nN, nE))) {
@@ -2805,9 +2811,9 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
             const RenderLaunch& Lp = launch_from_kernarg(L);
             w.next_event(scene_view(Lp), Lp, spec, cnt);
             PROF_END(2);
-            nT = __popcll(__ballot(w.stage == ST_TRAV));
-            nN = __popcll(__ballot(w.stage == ST_NEE));
-            nE = __popcll(__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+            nT = __popcll(ballot64(w.stage == ST_TRAV));
+            nN = __popcll(ballot64(w.stage == ST_NEE));
+            nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
         }
         // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
         if (nT >= phase_lanes || nT == max(max(nT, nS), max(nN, nE))) {
@@ -3120,7 +3126,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
     WorkFeed feed;
     feed.segment = blockIdx.x % kFeedSegments;
     for (;;) {
-        const unsigned long long idle_mask = __ballot(!busy);
+        const unsigned long long idle_mask = ballot64(!busy);
         const int idle = __popcll(idle_mask);
         if (!feed.drained && (idle >= kRefillLanes || idle == 64)) {
             feed_reserve(feed, L.next, L.n, L.reserve, lane);
@@ -3137,7 +3143,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
                 feed.next += min((uint32_t)idle, available);
             }
         }
-        if (__ballot(busy) == 0) {
+        if (ballot64(busy) == 0) {
             if (feed.drained) break;
             continue;
         }
@@ -3293,7 +3299,7 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderL
     const uint32_t lane_id = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
     uint32_t rank_in_wave = 0;
     for (uint32_t k = 0; k < 4; ++k) {
-        const unsigned long long m = __ballot(key == k);
+        const unsigned long long m = ballot64(key == k);
         if (key == k) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane_id) - 1ull));
         if (lane_id == 0) wave_counts[wave_id][k] = (uint32_t)__popcll(m);
     }
@@ -3317,16 +3323,16 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderL
     }
     const bool had_work = w.stage != ST_DONE;
     for (;;) {
-        const bool any_shade = __ballot(w.stage == ST_SHADE) != 0;
-        const bool any_nee = __ballot(w.stage == ST_NEE) != 0;
-        const bool any_end = __ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0;
+        const bool any_shade = ballot64(w.stage == ST_SHADE) != 0;
+        const bool any_nee = ballot64(w.stage == ST_NEE) != 0;
+        const bool any_end = ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0;
         if (!(any_shade || any_nee || any_end)) break; // every lane holds a ray to trace, or is done
         if (any_shade) w.shade(S, L, spec, cnt);
-        if (__ballot(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
-        if (__ballot(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
+        if (ballot64(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
+        if (ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
     }
     if (had_work) wf_store(P, slot, planes, w, spec, n_comp);
-    if (__ballot(w.stage == ST_TRAV) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u;
+    if (ballot64(w.stage == ST_TRAV) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u;
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -3438,7 +3444,7 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_tape_kernel(DevScene S0, Re
     const uint32_t lane_id = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
     uint32_t rank_in_wave = 0;
     for (uint32_t k = 0; k < 4; ++k) {
-        const unsigned long long m = __ballot(key == k);
+        const unsigned long long m = ballot64(key == k);
         if (key == k) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane_id) - 1ull));
         if (lane_id == 0) wave_counts[wave_id][k] = (uint32_t)__popcll(m);
     }
@@ -3472,19 +3478,19 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_tape_kernel(DevScene S0, Re
         const float* c = P.companions + slot;
         for (uint32_t k = 0; k < n_comp; ++k) spec.wl(k) = c[(size_t)k * P.n];
     }
-    if (__ballot(ending) != 0) {
+    if (ballot64(ending) != 0) {
         replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
         if (ending) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
     }
     for (;;) {
-        const bool any_shade = __ballot(w.stage == ST_SHADE) != 0;
-        const bool any_nee = __ballot(w.stage == ST_NEE) != 0;
+        const bool any_shade = ballot64(w.stage == ST_SHADE) != 0;
+        const bool any_nee = ballot64(w.stage == ST_NEE) != 0;
         if (!(any_shade || any_nee)) break; // every lane holds a ray to trace, is parked at its path's end, or is done
         if (any_shade) w.shade(S, L, spec, cnt);
-        if (__ballot(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
+        if (ballot64(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
     }
     if (had_work) wft_store(P, slot, planes, w, spec, n_comp);
-    if (__ballot(w.stage == ST_TRAV || w.stage == ST_EXPOSE) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u; // parked paths need another round too
+    if (ballot64(w.stage == ST_TRAV || w.stage == ST_EXPOSE) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u; // parked paths need another round too
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -3505,7 +3511,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
     WorkFeed feed;
     feed.segment = blockIdx.x % kFeedSegments;
     for (;;) {
-        const unsigned long long idle_mask = __ballot(!busy);
+        const unsigned long long idle_mask = ballot64(!busy);
         const int idle = __popcll(idle_mask);
         if (!feed.drained && (idle >= kRefillLanes || idle == 64)) {
             feed_reserve(feed, P.next, P.n, reserve, lane);
@@ -3534,7 +3540,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
                 feed.next += min((uint32_t)idle, available);
             }
         }
-        if (__ballot(busy) == 0) {
+        if (ballot64(busy) == 0) {
             if (feed.drained) break;
             continue;
         }
