@@ -112,6 +112,9 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
         }
     };
 
+    // What testing n primitives of one leaf costs, in primitive tests. PYR_SAH_PAIRS=1: the render kernels test a leaf's
+    // triangles two per step (DevPrimPair), so an odd triangle costs a whole step.
+    auto leaf_tests = [](uint32_t count) { return PYR_SAH_PAIRS ? (float)((count + 1u) & ~1u) : (float)count; };
     // Splits [begin,end) and returns mid; false when the range should become a leaf.
     auto split = [&](uint32_t begin, uint32_t end, uint32_t depth, const Box& box, const Box& cbox, uint32_t& mid) -> bool {
         uint32_t count = end - begin;
@@ -148,7 +151,7 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
                     left.grow(bin_box[b]);
                     lcnt += bin_count[b];
                     if (lcnt == 0 || right_count[b + 1] == 0) continue;
-                    float cost = left.half_area() * (float)lcnt + right_area[b + 1] * (float)right_count[b + 1];
+                    float cost = left.half_area() * leaf_tests(lcnt) + right_area[b + 1] * leaf_tests(right_count[b + 1]);
                     if (cost < best_cost) {
                         best_cost = cost;
                         best_axis = a;
@@ -161,7 +164,7 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
             // SAH termination: a leaf costs `count` primitive tests, a split costs one node visit plus the children.
             float parent_area = box.half_area();
             float split_cost = kSahNodeCost + (parent_area > 0.0f ? best_cost / parent_area : kInf);
-            if (count <= kMaxLeafPrims && (float)count <= split_cost) return false;
+            if (count <= kMaxLeafPrims && leaf_tests(count) <= split_cost) return false;
             float extent = cbox.hi[best_axis] - cbox.lo[best_axis];
             float scale = (float)kBins / extent;
             float lo = cbox.lo[best_axis];
