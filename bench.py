@@ -365,6 +365,8 @@ def main():
         torch.cuda.synchronize(device)
 
     wl = Workload(args.workload, args, torch, local_rank, world_size, rehearsal)
+    if rehearsal:
+        wl.collective = "torch.distributed.gather over gloo (PYRITE_BENCH_REHEARSAL: ranks share the GPUs; not a measurement)"
     if world_size > 1 and not rehearsal and wl.sharding == "tiles" and os.environ.get("PYRITE_BENCH_COLLECTIVE", "native") == "native":
         # The gather inside the library (pyr_render_simple_sharded: grouped ncclSend / ncclRecv). If the communicator cannot be
         # made on this node, every rank falls back TOGETHER to torch.distributed.gather over the same plan, and the line says so.

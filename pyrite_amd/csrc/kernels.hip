@@ -2771,7 +2771,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
 
     // the scene record as the phases see it (table pointers at the staged copies), rebuilt where a phase starts
     auto scene_view = [&](const RenderLaunch& Lp) {
-        if (!PYR_RELOAD_LAUNCH || LDS_SCENE) return S;
+        if (!PYR_RELOAD_LAUNCH || LDS_SCENE || INTERP) return S; // interpreter builds hand the record to run_interpreter by address: one copy in scratch, made once
         const uint32_t rows = (TAPE ? Lp.spectrum_samples + 1 + kTapeEagerSlots : 3 * Lp.spectrum_samples) + Lp.stack_lds;
         return stage_tables<LDS_TABLES ? 1 : 0, false>(scene_from_kernarg(S0), lds, rows * BLOCK);
     };
