@@ -3110,14 +3110,29 @@ DEV void feed_reserve(WorkFeed& f, uint32_t* cursors, uint32_t n, uint32_t reser
 // wait for the slowest ray of the wave: when kRefillLanes lanes are idle the wave takes that many rays from the batch with
 // ONE atomic (ballot + prefix count hand each idle lane its ray) and goes on stepping. On C3 the ray lengths are heavy
 // tailed (most rays see 3-6 nodes, rays that graze the mesh 50-100); a one-ray-per-lane kernel ran at 7 % lane occupancy.
+// Triangle-only scenes with a wide tree are walked as the render kernels walk them: the pair tree, straight-line steps
+// (trav_step_lean). PYR_INTERSECT_PAIRS=0 keeps the 48-byte records and the generic step (A/B).
+#ifndef PYR_INTERSECT_PAIRS
+#define PYR_INTERSECT_PAIRS 1
+#endif
+// 93 VGPRs: five waves per SIMD (8.35 -> 9.75 Grays/s with the pair tree and the lean step at four waves, 10.3 at five; six
+// waves spill: 6.1)
+#ifndef PYR_INTERSECT_WAVES
+#define PYR_INTERSECT_WAVES 5
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectLaunch L) {
+__global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(DevScene S, IntersectLaunch L) {
     extern __shared__ int lds_stack[];
     TravStack stack;
     stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
-    const SceneView view = wide_or_binary_view(S);
+    SceneView view = wide_or_binary_view(S);
+    const bool lean = PYR_INTERSECT_PAIRS && S.wide_nodes != nullptr && S.pair_prims != nullptr;
+    if (lean) {
+        view.nodes = reinterpret_cast<const float4*>(S.wide_pair_nodes);
+        view.pairs = reinterpret_cast<const float4*>(S.pair_prims);
+    }
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
     bool busy = false;
@@ -3148,7 +3163,7 @@ __global__ __launch_bounds__(BLOCK) void intersect_kernel(DevScene S, IntersectL
             continue;
         }
         for (int step = 0; step < kSteps; ++step) {
-            if (trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
+            if (lean ? trav_step_lean<COUNT>(view, t, stack, cnt, busy) : trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
                 PyrHit out;
                 out.distance = t.shape != PYR_HIT_NONE ? t.closest : PYR_INF;
                 out.shape = t.shape;
@@ -3495,13 +3510,18 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_tape_kernel(DevScene S0, Re
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, uint32_t reserve, uint32_t stack_lds, unsigned long long* counters) {
+__global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void wf_trav_kernel(DevScene S, WfPool P, uint32_t reserve, uint32_t stack_lds, unsigned long long* counters) {
     extern __shared__ int lds_stack[];
     TravStack stack;
     stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)stack_lds;
     Counters cnt{};
-    const SceneView view = wide_or_binary_view(S);
+    SceneView view = wide_or_binary_view(S);
+    const bool lean = PYR_INTERSECT_PAIRS && S.wide_nodes != nullptr && S.pair_prims != nullptr; // as intersect_kernel
+    if (lean) {
+        view.nodes = reinterpret_cast<const float4*>(S.wide_pair_nodes);
+        view.pairs = reinterpret_cast<const float4*>(S.pair_prims);
+    }
     const uint32_t lane = threadIdx.x & 63u;
     constexpr int kRefillLanes = 16, kSteps = 4;
     const size_t n = P.n;
@@ -3545,7 +3565,7 @@ __global__ __launch_bounds__(BLOCK) void wf_trav_kernel(DevScene S, WfPool P, ui
             continue;
         }
         for (int step = 0; step < kSteps; ++step) {
-            if (trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
+            if (lean ? trav_step_lean<COUNT>(view, t, stack, cnt, busy) : trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
                 if (!t.shadow) reinterpret_cast<float4*>(P.groups)[6 * n + slot] = make_float4(t.closest, __uint_as_float(t.shape), t.u, t.v);
                 P.stage[slot] = t.shadow ? (ST_NEE | WF_SHADOW | (t.blocked ? WF_BLOCKED : 0u)) : ST_SHADE;
                 busy = false;
