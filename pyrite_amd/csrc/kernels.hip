@@ -3134,7 +3134,13 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(D
         view.pairs = reinterpret_cast<const float4*>(S.pair_prims);
     }
     const uint32_t lane = threadIdx.x & 63u;
-    constexpr int kRefillLanes = 16, kSteps = 4;
+#ifndef PYR_INTERSECT_STEPS
+#define PYR_INTERSECT_STEPS 4
+#endif
+#ifndef PYR_INTERSECT_REFILL
+#define PYR_INTERSECT_REFILL 16
+#endif
+    constexpr int kRefillLanes = PYR_INTERSECT_REFILL, kSteps = PYR_INTERSECT_STEPS;
     bool busy = false;
     uint32_t ray = 0;
     Trav t{};
