@@ -2626,7 +2626,11 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 q_prog.data = S.spectrum_data + e[5];
                 q_prog.id = slot_program[slot];
                 VmInput in{wl, mk(0, 0, 0), mk(0, 0, 0)};
+#ifdef PYR_REPLAY_NOEAGER_EVAL // timing ablation (the film is wrong): what the per-item look-ups of the spectrum-reading programs cost
+                spectral_values[slot * BLOCK] = in.wavelength * 1.0e-3f;
+#else
                 spectral_values[slot * BLOCK] = eval_prepared<false>(S, q_prog, in);
+#endif
             }
         }
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
