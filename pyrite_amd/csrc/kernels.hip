@@ -3809,8 +3809,14 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.stack_lds = launch.scheduler == 1 || launch.scheduler == 3 ? short_stack_levels(scene, render_lds_bytes(scene, launch), PYR_SM_WAVES) : scene.stack_depth;
     // the split scheduler walks four-child trees with triangle pairs only, keeps its slots in the stack rows and has no
     // interpreter form: anything else runs on the stage scheduler
-    if (launch.scheduler == 3 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene) || launch.stack_lds < kSplitRows))
+    if (launch.scheduler == 3 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene) || launch.stack_lds < kSplitRows)) {
+        if (const char* strict = std::getenv("PYRITE_SCHEDULER_STRICT")) // test switch: a forced scheduler that cannot run is an error, not a fallback
+            if (*strict == '1') {
+                g_kernel_error = "PYRITE_SCHEDULER=split cannot run this scene (needs the four-child pair tree, no interpreter programs, >= 11 LDS stack levels)";
+                return PYR_ERR_UNSUPPORTED;
+            }
         launch.scheduler = 1;
+    }
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";

@@ -276,6 +276,7 @@ def test_split_scheduler_on_a_c3_shaped_scene(glass, gpu_lib, monkeypatch):
     from pyrite_amd.renderer import Camera, Renderer, World
 
     monkeypatch.setenv("PYRITE_SCHEDULER", "split")
+    monkeypatch.setenv("PYRITE_SCHEDULER_STRICT", "1")  # the split kernel itself, not its fallback to the stage scheduler
     project = scenes.c3_mesh_in_box(width=50, height=30, pixel_samples=5, glass=glass, bounces=20 if glass else None)
     world = World(scenes.c3_flat(segments=96, sides=48, glass=glass))
     r = Renderer.from_project(project["renderer"], seed=13)
