@@ -649,7 +649,9 @@ int reserve_tape(PyrScene* scene, RenderLaunch& L, hipStream_t stream) {
     if (!scene->tape_overflow.ptr) {
         int rc = scene->tape_overflow.alloc(sizeof(uint32_t));
         if (rc != PYR_OK) return rc;
-        HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
+        // cleared on the stream the render is enqueued on: a null-stream memset is not ordered against a kernel on a
+        // hipStreamNonBlocking stream (the multi-device entries use such streams)
+        HIP_TRY(hipMemsetAsync(scene->tape_overflow.ptr, 0, sizeof(uint32_t), stream));
     }
     L.tape_overflow = (uint32_t*)scene->tape_overflow.ptr;
     return PYR_OK;
@@ -710,6 +712,10 @@ int check_tape_overflow(PyrScene* scene) {
     if (word == 2) return fail(PYR_ERR_DEVICE, "the split scheduler gave up waiting (a wave polled its LDS slots past the spin limit): the film of that render is invalid");
     return fail(PYR_ERR_DEVICE, "a path appended more records than the spectral tape's bound allows: the film of that render is invalid");
 }
+
+// For the translation units that enqueue renders without waiting for them (multi.cpp): the word itself.
+uint32_t* scene_overflow_word(PyrScene* scene) { return scene ? (uint32_t*)scene->tape_overflow.ptr : nullptr; }
+int scene_check_overflow(PyrScene* scene) { return check_tape_overflow(scene); }
 
 RenderLaunch make_launch(const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* p, const TilePlan& plan) {
     RenderLaunch L{};

@@ -8,18 +8,20 @@ import oracle
 from pyrite_amd import scenes
 from pyrite_amd.project import (blackbody, camera, fresnel, light, light_source, material, mix, renderer, rgb, shape, spectrum, texture, transform,
                                 vector)
-from test_gpu_parity import rel_l2
+from test_gpu_parity import OBSERVED, rel_l2
 
 f32 = np.float32
 
 
 def assert_parity(gpu_film, cpu_film):
-    """As test_gpu_parity.assert_parity, for images of a few hundred pixels: the two sides add the same exposures to a grain
-    in different orders (float atomics), and a pixel that sums values of very different size can differ by more than 1e-5
-    relative; allow two such pixels (or 0.2 %), none beyond 1e-3."""
+    """As test_gpu_parity.assert_parity: identical weights, every pixel within 1e-5 (observed on these scenes: 1e-7). A
+    sample whose path crosses two primitives at the same f32 distance may resolve differently on the two sides (DESIGN.md 5,
+    soup 315 of the long campaign) and would show up here as a failure to be traced, not as a tolerated outlier."""
     assert np.array_equal(gpu_film.grains[..., 1], cpu_film.grains[..., 1]), "film weights differ"
     e = rel_l2(gpu_film, cpu_film)
-    assert (e > 1e-5).sum() <= max(2, 0.002 * e.size) and e.max() <= 1e-3, "relL2: %d of %d pixels above 1e-5, max %.3g" % ((e > 1e-5).sum(), e.size, e.max())
+    name = __import__("os").environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    OBSERVED[name] = max(OBSERVED.get(name, 0.0), float(e.max()))
+    assert e.max() <= 1e-5, "relL2: %d of %d pixels above 1e-5, max %.3g" % ((e > 1e-5).sum(), e.size, e.max())
     assert not np.isnan(gpu_film.grains).any()
 
 

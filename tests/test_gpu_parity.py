@@ -2,11 +2,12 @@
 
 Stated tolerance (north_star: "within a stated per-pixel spectral L2 tolerance"): with s = acc / weight per bin,
     relL2(pixel) = ||s_gpu - s_cpu||_2 / (||s_cpu||_2 + 1e-6)
-must be <= 1e-5 for at least 99.9 % of the pixels, and the film WEIGHTS (integer sample counts per bin) must be identical.
-The kernels and the oracle perform the same f32 operations in the same order (no FMA contraction, transcendentals rounded
-once from f64, the same RNG streams), so paths agree bit for bit and only the order of the float atomics differs; the
-0.1 % allowance covers the ~1e-8-per-call double-rounding cases of the transcendentals. Integer / index results
-(hit shapes, counters, weights) must be exact."""
+must be <= 1e-5 for EVERY pixel (round 3: no share of outliers is allowed any more), and the film WEIGHTS (integer sample
+counts per bin) must be identical. The kernels and the oracle perform the same f32 operations in the same order (no FMA
+contraction, the same Cephes transcendentals, the same RNG streams), so paths agree bit for bit and only the order of the
+float atomics differs: the largest per-pixel value any of the 70 film comparisons of the suite saw on an MI355X is 1.3e-7
+(profiles/r03_parity_observed.json; every assertion message and gpurun_out/parity_observed.json carry the observed
+maximum). Integer / index results (hit shapes, counters, weights) must be exact."""
 import importlib.util
 import json
 import os
@@ -20,7 +21,8 @@ from pyrite_amd.project import renderer
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL, FRACTION = 1e-5, 0.999
+TOL = 1e-5
+OBSERVED = {}  # test id -> largest per-pixel relL2 any assert_parity of that test saw (written out by conftest.py)
 
 
 def rel_l2(gpu_film, cpu_film):
@@ -31,7 +33,11 @@ def rel_l2(gpu_film, cpu_film):
 def assert_parity(gpu_film, cpu_film):
     assert np.array_equal(gpu_film.grains[..., 1], cpu_film.grains[..., 1]), "film weights differ"
     e = rel_l2(gpu_film, cpu_film)
-    assert (e <= TOL).mean() >= FRACTION, "relL2: median %.3g p99 %.3g max %.3g" % (np.median(e), np.percentile(e, 99), e.max())
+    worst = float(e.max()) if e.size else 0.0
+    name = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    OBSERVED[name] = max(OBSERVED.get(name, 0.0), worst)
+    message = "relL2: median %.3g p99 %.3g max %.3g (pixel %d)" % (np.median(e), np.percentile(e, 99), worst, int(e.argmax()))
+    assert worst <= TOL, message
     assert not np.isnan(gpu_film.grains).any()
 
 
@@ -523,6 +529,75 @@ def test_full_size_c3_properties(gpu_lib):
     film = film.cpu().numpy()
     assert np.array_equal(film[..., 1], whole.grains[..., 1])
     assert np.allclose(film[..., 0], whole.grains[..., 0], rtol=1e-4, atol=1e-6)
+
+    # the oracle on tiles of the full-size image, one by one, at 4 spp (tile-level parity at BASELINE size: the contract
+    # config's diffuse 819 k-triangle mesh with next-event estimation on it, tracer.rs:257-280, :347-442): two tiles on the
+    # mesh, one at its silhouette, two on the floor in the mesh's shadow, one in the wall / floor corner
+    r.pixel_samples = 4
+    sc = oracle.OracleScene(world)
+    tiles_x = W // 32
+    mesh_tests = []
+    for row, col in ((24, 30), (22, 20), (26, 38), (30, 28), (29, 36), (31, 12)):
+        tile = tiles_x * row + col
+        cpu, gpu = r.new_film(W, H), r.new_film(W, H)
+        cc = sc.render(r, cam, cpu, threads=8, tile_range=(tile, tile + 1))
+        gc = r.render(gpu, cam, world, tile_range=(tile, tile + 1), counters=True)
+        for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+            assert gc[key] == cc[key], (row, col, key)
+        assert cc["samples"] == 32 * 32 * 4 and cc["shadow_rays"] > cc["samples"]  # next-event estimation ran
+        assert_parity(gpu, cpu)
+        mesh_tests.append(gc["triangle_tests"] / gc["extension_rays"])
+    assert max(mesh_tests) > 2 * min(mesh_tests)  # the tiles differ in how much of the mesh they see
+    sc.close()
+    world.close()
+
+
+def c3_bench_rays(n, seed=1):
+    """bench.py's `traversal_roofline` batch: uniform origins in the x10 Cornell box, uniform directions."""
+    rng = np.random.RandomState(seed)
+    o = rng.uniform([-55, 1, 1], [-1, 55, 54], size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def camera_rays(cam, n, seed, aspect=1080.0 / 1920.0):
+    """Primary rays of a pinhole camera through uniformly drawn view-plane positions (Camera::ray_towards, cameras.rs:70-97)."""
+    c = cam.c
+    m = np.array(list(c.cam_to_world), dtype=np.float64).reshape(4, 4).T  # cgmath matrices are column-major
+    rng = np.random.RandomState(seed)
+    x, y = rng.uniform(-1, 1, n), rng.uniform(-aspect, aspect, n)
+    target = np.stack([x / c.view_plane * c.focus_distance, -y / c.view_plane * c.focus_distance, np.full(n, -c.focus_distance)], axis=1)
+    d = target / np.linalg.norm(target, axis=1, keepdims=True)
+    d = d @ m[:3, :3].T
+    o = np.broadcast_to(m[:3, 3], (n, 3))
+    return np.concatenate([o, d], axis=1).astype(np.float32)
+
+
+def test_closest_hit_on_the_full_c3_mesh(gpu_lib):
+    """World::intersect (world.rs:273-299) on the FULL 819,212-triangle C3 scene -- the tree (four-child nodes, triangle pairs)
+    and the kernel (intersect_kernel, straight-line steps, five waves per SIMD) behind bench.py's `traversal_roofline` --
+    against the oracle: 250 k rays of the very generator bench.py uses, 150 k camera rays (coherent, most of them end on
+    the mesh) and 50 k shadow-like rays towards the lamp. Bit-exact distance, shape and barycentrics; every difference a
+    proven tie (assert_same_hits)."""
+    world, cam, r, _ = scenes.build(scenes.c3_mesh_in_box(64, 36, 1), seed=1)
+    info = world.bvh_info()
+    assert info["num_primitives"] == 819212
+    rng = np.random.RandomState(4)
+    floor = rng.uniform([-55, 1, 0.01], [-1, 55, 0.01], size=(50000, 3))
+    lamp = rng.uniform([-34.3, 22.7, 54.79], [-21.3, 33.2, 54.79], size=(50000, 3))  # box.obj's light quad x10
+    to_lamp = lamp - floor
+    to_lamp /= np.linalg.norm(to_lamp, axis=1, keepdims=True)
+    rays = np.concatenate([c3_bench_rays(250000), camera_rays(cam, 150000, 2), np.concatenate([floor, to_lamp], axis=1).astype(np.float32)])
+    sc = oracle.OracleScene(world)
+    ohits, _ = sc.intersect(rays)
+    ghits, _, counters = world.intersect(rays, want_counters=True)
+    ties = assert_same_hits(ohits, ghits, world, rays)
+    assert ties < 0.001 * len(rays), ties
+    on_mesh = (ohits["shape"] >> 30 == 1) & ((ohits["shape"] & 0x3FFFFFFF) >= 12)  # the box's 12 triangles come first
+    assert on_mesh[:250000].mean() > 0.05 and on_mesh[250000:400000].mean() > 0.08 and (ohits["shape"] != 0xFFFFFFFF).mean() > 0.85  # the box is open at the front
+    assert counters["triangle_tests"] > len(rays) and counters["box_tests"] > 10 * len(rays)
+    sc.close()
     world.close()
 
 
