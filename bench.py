@@ -306,6 +306,8 @@ def timed_steps(wl, steps, warmup, seed, fence, dist, world_size):
     wl.renderer.seed = seed
     fence()
     elapsed = time.perf_counter() - t0
+    if getattr(wl, "native", None) is not None:
+        wl.native.status()  # raises if some rank's kernels flagged their film invalid, or the communicator died
     if world_size > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=wl.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -414,14 +414,26 @@ int pyr_film_blocks_assemble_device(const PyrFilmDesc* film, const PyrRenderPara
 #define PYR_COMM_ID_BYTES 128
 typedef struct PyrComm PyrComm;
 int pyr_comm_unique_id(uint8_t id_out[PYR_COMM_ID_BYTES]);
+/* A world of one rank needs no RCCL communicator and gets none -- unless the environment says PYRITE_FORCE_RCCL=1: then
+ * ncclCommInitRank(nranks = 1) really runs and the rank's blocks travel through a grouped self ncclSend / ncclRecv, which
+ * exercises the gather's code on a single GPU. pyr_comm_uses_rccl tells which kind a communicator is (1 / 0). */
 int pyr_comm_create(const uint8_t id[PYR_COMM_ID_BYTES], int rank, int num_ranks, int device, PyrComm** out_comm);
+int pyr_comm_uses_rccl(const PyrComm* comm);
 void pyr_comm_destroy(PyrComm* comm);
 
-/* This rank's part of a sharded render, enqueued on `hip_stream` without synchronising: of the tiles `params` selects
- * (normally all: tile_begin = tile_end = 0, tile_stride <= 1) rank r renders every num_ranks-th starting at the r-th,
- * sends its blocks to rank 0 (grouped ncclSend / ncclRecv: the one gather), and rank 0 adds everybody's blocks into
- * `film_device_rank0` (a whole-image film on rank 0's device; ignored on the other ranks, may be NULL there).
- * `scene` must live on the communicator's device. Working buffers are kept on the communicator between calls. */
+/* This rank's part of a sharded render, enqueued on `hip_stream`: of the tiles `params` selects (normally all:
+ * tile_begin = tile_end = 0, tile_stride <= 1) rank r renders every num_ranks-th starting at the r-th, sends its blocks
+ * to rank 0 (grouped ncclSend / ncclRecv: the one gather), and rank 0 adds everybody's blocks into `film_device_rank0` (a
+ * whole-image film on rank 0's device; ignored on the other ranks, may be NULL there). `scene` must live on the
+ * communicator's device. Working buffers are kept on the communicator between calls.
+ *   Failures never leave a peer blocked (the reference's workers report to one collecting thread, renderer/mod.rs:181-183):
+ * before anything is sent the ranks agree -- one one-word ncclAllReduce, waited for on the host -- that every rank got
+ * through its argument checks and buffer growth; if one did not, EVERY rank returns an error and nothing is rendered. What
+ * fails later (a launch, or the kernels flagging their own film invalid) travels in a trailer grain behind each rank's
+ * blocks, so every rank still enters the gather; pyr_comm_status() reports it on rank 0 (every rank's trailer) and on the
+ * sender (its own) once `hip_stream` has been waited for: PYR_OK, or PYR_ERR_DEVICE naming the rank -- the film is invalid
+ * then. An error inside the collective calls aborts the communicator (ncclCommAbort); every later call on it fails. */
+int pyr_comm_status(PyrComm* comm);
 int pyr_render_simple_sharded(PyrComm* comm, PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film,
                               const PyrRenderParams* params, PyrGrain* film_device_rank0, void* hip_stream);
 

@@ -262,6 +262,8 @@ ENTRY_POINTS = {
     "pyr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pyr_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pyr_comm_destroy": (None, [C.c_void_p]),
+    "pyr_comm_uses_rccl": (C.c_int, [C.c_void_p]),
+    "pyr_comm_status": (C.c_int, [C.c_void_p]),
     "pyr_render_simple_sharded": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(PyrCamera), C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams), C.c_void_p, C.c_void_p],

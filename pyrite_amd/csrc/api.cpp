@@ -713,9 +713,15 @@ int check_tape_overflow(PyrScene* scene) {
     return fail(PYR_ERR_DEVICE, "a path appended more records than the spectral tape's bound allows: the film of that render is invalid");
 }
 
-// For the translation units that enqueue renders without waiting for them (multi.cpp): the word itself.
+} // namespace
+
+namespace pyr {
+// For the translation units that enqueue renders without waiting for them (multi.cpp): the word itself, and its check.
 uint32_t* scene_overflow_word(PyrScene* scene) { return scene ? (uint32_t*)scene->tape_overflow.ptr : nullptr; }
 int scene_check_overflow(PyrScene* scene) { return check_tape_overflow(scene); }
+} // namespace pyr
+
+namespace {
 
 RenderLaunch make_launch(const PyrCamera* camera, const PyrFilmDesc* film, const PyrRenderParams* p, const TilePlan& plan) {
     RenderLaunch L{};

@@ -177,24 +177,42 @@ def render_sharded(render_share, width, height, bins, tile_size, device, group=N
 
 class NativeSharded:
     """pyr_comm_* + pyr_render_simple_sharded: the render, the RCCL gather and the assembly all inside libpyrite_gpu.so.
-    The communicator id travels over the torch.distributed group that is already up (any backend)."""
+    The communicator id travels over the torch.distributed group that is already up (any backend). Construction is
+    collective: rank 0 broadcasts (ok, id) -- if it could not obtain an id every rank raises, none is left waiting -- and
+    every rank must then attempt pyr_comm_create (ncclCommInitRank is itself collective)."""
 
     def __init__(self, device_index, group=None):
-        from ._lib import check, lib
+        from ._lib import PyriteGpuError, check, lib
 
         self._lib, self._check = lib(), check
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device_index = int(device_index)
-        ident = (C.c_uint8 * abi.PYR_COMM_ID_BYTES)()
-        if self.world_size > 1:
-            if self.rank == 0:
-                check(self._lib.pyr_comm_unique_id(ident))
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            ident = (C.c_uint8 * abi.PYR_COMM_ID_BYTES).from_buffer_copy(box[0])
         self.handle = C.c_void_p()
+        ident = (C.c_uint8 * abi.PYR_COMM_ID_BYTES)()
+        forced = os.environ.get("PYRITE_FORCE_RCCL") == "1"
+        if self.world_size > 1:
+            box = [None]
+            if self.rank == 0:
+                rc = self._lib.pyr_comm_unique_id(ident)
+                box = [(rc, bytes(ident) if rc == 0 else self._lib.pyr_last_error().decode())]
+            dist.broadcast_object_list(box, src=0, group=group)
+            rc, payload = box[0]
+            if rc != 0:
+                raise PyriteGpuError(rc, "rank 0 could not obtain a communicator id: %s" % payload)
+            ident = (C.c_uint8 * abi.PYR_COMM_ID_BYTES).from_buffer_copy(payload)
+        elif forced:
+            check(self._lib.pyr_comm_unique_id(ident))
         check(self._lib.pyr_comm_create(ident, self.rank, self.world_size, self.device_index, C.byref(self.handle)))
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.pyr_comm_uses_rccl(self.handle))
+
+    def status(self):
+        """After the stream of the last render has been waited for: raises if some rank flagged its film invalid (rank 0
+        sees every rank's verdict, the others their own) or the communicator is dead."""
+        self._check(self._lib.pyr_comm_status(self.handle))
 
     def render(self, renderer, camera, world, film_desc, film_tensor, stream=0):
         """Adds one sharded render into `film_tensor` (rank 0: float32 [height, width, bins, 2] on this rank's GPU; None elsewhere)."""

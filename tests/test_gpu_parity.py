@@ -689,8 +689,9 @@ def test_native_multi_device_render_equals_the_single_device_film(ranks, gpu_lib
 
 
 def test_native_sharded_entry_with_one_rank(gpu_lib):
-    """pyr_comm_create / pyr_render_simple_sharded for a world of one: the communicator, the block buffer and the assembly
-    without a peer (the RCCL calls themselves need a second GPU and run in bench.py --gpus N)."""
+    """pyr_comm_create / pyr_render_simple_sharded for a world of one WITHOUT a communicator (the default for one rank): the
+    block buffer and the assembly in place. The same entry with a real one-rank RCCL communicator, and the multi-rank flow,
+    are in tests/test_gpu_multi.py."""
     import torch
 
     from pyrite_amd import distributed as pdist
@@ -700,8 +701,10 @@ def test_native_sharded_entry_with_one_rank(gpu_lib):
     dev = torch.device("cuda", 0)
     film = torch.zeros((48, 64, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
     comm = pdist.NativeSharded(0)
+    assert not comm.uses_rccl
     comm.render(r, cam, world, whole.desc(), film, stream=torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
+    comm.status()
     comm.close()
     assert np.array_equal(film.cpu().numpy()[..., 1], whole.grains[..., 1])
     assert np.allclose(film.cpu().numpy(), whole.grains, rtol=1e-5)
