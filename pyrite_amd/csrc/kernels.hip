@@ -687,30 +687,49 @@ DEV bool sphere_box_guard(f3 center, float radius, f3 o, f3 d, float closest, bo
     return entry >= 0.0f && (any_hit || entry < closest);
 }
 
-// Both children of a node at once. The node stores the bounds interleaved (bvh.h Node64: q0 = lo.x lo.y, q1 = lo.z hi.x,
-// q2 = hi.y hi.z, each as a (child 0, child 1) pair), so the twelve plane distances are six v_pk_fma_f32:
-// t = bound * inv - o * inv. That form rounds differently from math.rs:184-207's (bound - o) * inv; the boxes are this
-// library's own and are padded at build time so that the test stays conservative (bvh.cpp), and NaN (0 * inf on a ray
-// parallel to a slab) drops out of min / max as it does in the reference's f32::min / max.
+// Both children of a node at once. The node stores the bounds interleaved (bvh.h Node64: lo.x lo.y | lo.z hi.x | hi.y hi.z,
+// each as a (child 0, child 1) pair), so the twelve plane distances are six v_pk_fma_f32: t = bound * inv - o * inv. That
+// form rounds differently from math.rs:184-207's (bound - o) * inv; the boxes are this library's own and are padded at build
+// time so that the test stays conservative (bvh.cpp).
 // 1 / direction for the box tests only: v_rcp_f32 (1 ulp) instead of an IEEE division (~12 instructions each). The boxes are
 // padded by 16 ulps of the scene extent, which covers it; primitive tests never see this value. rcp(+-0) = +-inf as 1 / 0.
 DEV f3 box_reciprocal(f3 d) { return mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)); }
 
 typedef float f2v __attribute__((ext_vector_type(2)));
-DEV void slab_pair(const float4 q0, const float4 q1, const float4 q2, f3 o, f3 inv, float& e0, float& e1) {
+// Planes are picked by the sign of the ray's direction: `node` points at a Node64, sx / sy / sz are 0 for a
+// positive direction component and 24 for a negative one (the byte distance from lo_* to hi_* in the node), so the six 8-byte
+// loads fetch, per axis, the (child 0, child 1) pair of the plane the ray meets first and of the one it meets last; entry =
+// max of the near distances, exit = min of the far ones -- 4 min / max instead of 12. t = bound * inv - o * inv is monotonic in
+// `bound`, so the near distance IS min(t_lo, t_hi), value for value, unless 0 * inf or inf - inf makes one of the two NaN (a
+// direction component of exactly zero): a min / max over both planes (rounds 1-2) then used the other one for both entry and exit
+// and rejected boxes the ray lies inside of on that axis (an axis-parallel ray through the Cornell box missed everything); here the NaN
+// drops out of max / min and the axis does not constrain -- what math.rs:184-207's (bound - o) * inv gives for such a ray.
+typedef __attribute__((address_space(1))) const f2v global_f2v;
+template <bool GLOBAL>
+DEV void slab_pair_signed(const float4* nodes, uint32_t node, uint32_t sx, uint32_t sy, uint32_t sz, f3 o, f3 inv, float& e0, float& e1, int& c0, int& c1) {
+    // one (uniform) base and a 32-bit byte offset per lane: an SGPR-based global_load, or a plain LDS address
+    const char* base = reinterpret_cast<const char*>(nodes);
+    auto pair = [&](uint32_t byte_offset) -> f2v {
+        if constexpr (GLOBAL) return *(global_f2v*)(base + byte_offset);
+        return *reinterpret_cast<const f2v*>(base + byte_offset);
+    };
+    const uint32_t at = node << 6, ax = at + sx, ay = at + sy, az = at + sz;
+    const f2v nx = pair(ax), fx = pair(ax ^ 24u), ny = pair(ay + 8u), fy = pair((ay ^ 24u) + 8u), nz = pair(az + 16u), fz = pair((az ^ 24u) + 16u);
+    const f2v ch = pair(at + 48u);
     const f2v ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     const float ox = -(o.x * inv.x), oy = -(o.y * inv.y), oz = -(o.z * inv.z);
     const f2v nox = {ox, ox}, noy = {oy, oy}, noz = {oz, oz};
-    const f2v lx = __builtin_elementwise_fma((f2v){q0.x, q0.y}, ix, nox), hx = __builtin_elementwise_fma((f2v){q1.z, q1.w}, ix, nox);
-    const f2v ly = __builtin_elementwise_fma((f2v){q0.z, q0.w}, iy, noy), hy = __builtin_elementwise_fma((f2v){q2.x, q2.y}, iy, noy);
-    const f2v lz = __builtin_elementwise_fma((f2v){q1.x, q1.y}, iz, noz), hz = __builtin_elementwise_fma((f2v){q2.z, q2.w}, iz, noz);
-    const float tmin0 = fmaxf(fmaxf(fminf(lx.x, hx.x), fminf(ly.x, hy.x)), fminf(lz.x, hz.x));
-    const float tmax0 = fminf(fminf(fmaxf(lx.x, hx.x), fmaxf(ly.x, hy.x)), fmaxf(lz.x, hz.x));
-    const float tmin1 = fmaxf(fmaxf(fminf(lx.y, hx.y), fminf(ly.y, hy.y)), fminf(lz.y, hz.y));
-    const float tmax1 = fminf(fminf(fmaxf(lx.y, hx.y), fmaxf(ly.y, hy.y)), fmaxf(lz.y, hz.y));
-    e0 = (tmax0 >= tmin0 && tmax0 >= 0.0f) ? fmaxf(tmin0, 0.0f) : -1.0f;
-    e1 = (tmax1 >= tmin1 && tmax1 >= 0.0f) ? fmaxf(tmin1, 0.0f) : -1.0f;
+    const f2v tnx = __builtin_elementwise_fma(nx, ix, nox), tfx = __builtin_elementwise_fma(fx, ix, nox);
+    const f2v tny = __builtin_elementwise_fma(ny, iy, noy), tfy = __builtin_elementwise_fma(fy, iy, noy);
+    const f2v tnz = __builtin_elementwise_fma(nz, iz, noz), tfz = __builtin_elementwise_fma(fz, iz, noz);
+    const float tmin0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x), tmax0 = fminf(fminf(tfx.x, tfy.x), tfz.x);
+    const float tmin1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y), tmax1 = fminf(fminf(tfx.y, tfy.y), tfz.y);
+    const float entry0 = fmaxf(tmin0, 0.0f), entry1 = fmaxf(tmin1, 0.0f);
+    e0 = tmax0 >= entry0 ? entry0 : -1.0f; // tmax >= max(tmin, 0) is (tmax >= tmin) & (tmax >= 0); a NaN exit fails it
+    e1 = tmax1 >= entry1 ? entry1 : -1.0f;
+    c0 = __float_as_int(ch.x), c1 = __float_as_int(ch.y);
 }
+DEV uint32_t binary_sign_offset(float component) { return (__float_as_uint(component) >> 31) * 24u; }
 
 // World::intersect (world.rs:273-299). SHADOW = false: closest hit with DIST_EPSILON < d < closest.
 // SHADOW = true: answers trace_direct's visibility question (tracer.rs:381-389) -- "is there a hit with
@@ -738,6 +757,7 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
         }
     }
     const f3 inv = box_reciprocal(d);
+    const uint32_t sign_x = binary_sign_offset(d.x), sign_y = binary_sign_offset(d.y), sign_z = binary_sign_offset(d.z);
     const float limit_cull = limit * 1.001f + 1.0e-3f; // +inf stays +inf
     int sp = 0;
     int node = 0;
@@ -746,10 +766,10 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
     // kind of step most lanes wait for (the minority keeps its place) was slower on C2: 636.
     for (;;) {
         if (node >= 0) {
-            const float4 n0 = nodes[4 * node + 0], n1 = nodes[4 * node + 1], n2 = nodes[4 * node + 2], n3 = nodes[4 * node + 3];
             if (COUNT) cnt.box_tests += 2;
             float e0, e1;
-            slab_pair(n0, n1, n2, o, inv, e0, e1);
+            int c0, c1;
+            slab_pair_signed<false>(nodes, (uint32_t)node, sign_x, sign_y, sign_z, o, inv, e0, e1, c0, c1);
             bool h0, h1;
             if (SHADOW) {
                 // A box can be skipped only if nothing in it can block. Its computed entry distance and a primitive's computed
@@ -763,7 +783,6 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
                 h0 = e0 >= 0.0f && e0 < closest; // bvh.rs:213: skip when distance >= max_distance
                 h1 = e1 >= 0.0f && e1 < closest;
             }
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (h0 && h1) {
                 bool swap = e1 < e0;
                 node = swap ? c1 : c0;
@@ -1702,6 +1721,10 @@ enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EX
 
 struct Trav { // resumable World::intersect
     f3 o, d, inv;
+    // Byte offsets (0 or 48) of the planes the ray meets FIRST on each axis inside a Node128: lo_* for a positive direction
+    // component, hi_* (48 bytes further) for a negative one; the far plane is at the offset ^ 48. Set with `inv` where a ray is
+    // about to be stepped (trav_ray_signs); the straight-line step loads near and far planes directly (wide_node_children).
+    uint32_t nx = 0, ny = 0, nz = 0;
     // `closest` is the distance boxes are cut off at: the closest hit so far for an extension ray; for a shadow ray the square
     // root of the blocking limit with its 0.1 % margin (traverse<>'s limit_cull) -- one comparison serves both kinds of ray, and
     // the half-ulp of the root is far inside that margin. A shadow ray never reads it as a hit distance.
@@ -1714,6 +1737,11 @@ struct Trav { // resumable World::intersect
 };
 constexpr int kNoNode = INT32_MIN; // trav_step_postponed: t.node when the lane holds no subtree any more (never a leaf code: api.cpp keeps first + count < 2^28)
 
+DEV void trav_ray_signs(Trav& t) {
+    t.nx = (__float_as_uint(t.d.x) >> 31) * 48u;
+    t.ny = (__float_as_uint(t.d.y) >> 31) * 48u;
+    t.nz = (__float_as_uint(t.d.z) >> 31) * 48u;
+}
 // Puts a query whose ray, limit and plane results are set at the root of the tree.
 DEV float shadow_cutoff(float limit) { return sqrtf(limit * 1.001f + 1.0e-3f); } // +inf stays +inf; a negative limit gives NaN: nothing passes
 // (t.inv is NOT set here: the kernels compute it where a ray is about to be stepped -- the stage scheduler at every entry of
@@ -1782,7 +1810,13 @@ struct TravStack {
 // others are pushed far to near, so they pop nearest first. Returns true when the traversal has finished.
 // The four box tests of a node and the order of its children: c[] = the children that are hit, nearest first (entry distance
 // e[]), the others INT32_MIN at the end.
-template <bool COUNT>
+// SIGNED: the first three vectors are the planes the ray meets first on each axis and the other three the ones it meets last
+// (the caller picked them by the sign of the direction, trav_ray_signs), so entry = max of the near distances and exit = min of
+// the far ones: 12 min / max per node instead of 36. t = bound * inv - o * inv is monotonic in `bound`, so the near distance IS
+// min(t_lo, t_hi) of the unsigned form, value for value -- except where 0 * inf or inf - inf makes one of the pair NaN (a
+// direction component of exactly zero): the unsigned form then takes the other one for both entry and exit and can reject a
+// box the ray is inside of on that axis; here a NaN plane distance drops out of max3 / min3 and the axis does not constrain.
+template <bool COUNT, bool SIGNED = false>
 DEV void wide_node_children(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, const Trav& t,
                             Counters& cnt, float (&e)[4], int (&c)[4]) {
     const f2v ix = {t.inv.x, t.inv.x}, iy = {t.inv.y, t.inv.y}, iz = {t.inv.z, t.inv.z};
@@ -1801,8 +1835,10 @@ DEV void wide_node_children(const float4 lx, const float4 ly, const float4 lz, c
         // no branches in here: the backend knows an fma result is never a signalling NaN only inside one basic block, and quiets
         // every min / max operand again (a v_max x, x, x each) on the far side of one
         for (int k = 0; k < 4; ++k) {
-            const float tmin = fmaxf(fmaxf(fminf(tl[k][0], th[k][0]), fminf(tl[k][1], th[k][1])), fminf(tl[k][2], th[k][2]));
-            const float tmax = fminf(fminf(fmaxf(tl[k][0], th[k][0]), fmaxf(tl[k][1], th[k][1])), fmaxf(tl[k][2], th[k][2]));
+            const float tmin = SIGNED ? fmaxf(fmaxf(tl[k][0], tl[k][1]), tl[k][2])
+                                      : fmaxf(fmaxf(fminf(tl[k][0], th[k][0]), fminf(tl[k][1], th[k][1])), fminf(tl[k][2], th[k][2]));
+            const float tmax = SIGNED ? fminf(fminf(th[k][0], th[k][1]), th[k][2])
+                                      : fminf(fminf(fmaxf(tl[k][0], th[k][0]), fmaxf(tl[k][1], th[k][1])), fmaxf(tl[k][2], th[k][2]));
             const float entry = fmaxf(tmin, 0.0f);
             if (COUNT) cnt.box_tests += c[k] != INT32_MIN ? 1u : 0u;
             // tmax >= max(tmin, 0) is (tmax >= tmin) & (tmax >= 0); an unused slot's box is NaN (bvh.cpp) and fails it
@@ -1824,12 +1860,12 @@ DEV void wide_node_children(const float4 lx, const float4 ly, const float4 lz, c
     order(1, 3);
     order(1, 2);
 }
-template <bool COUNT, bool POSTPONE = false>
+template <bool COUNT, bool POSTPONE = false, bool SIGNED = false>
 DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, Trav& t,
                          TravStack& stack, Counters& cnt) {
     float e[4];
     int c[4];
-    wide_node_children<COUNT>(lx, ly, lz, hx, hy, hz, ch, t, cnt, e, c);
+    wide_node_children<COUNT, SIGNED>(lx, ly, lz, hx, hy, hz, ch, t, cnt, e, c);
     if (c[0] == INT32_MIN) { // nothing hit
         if (t.sp == 0) {
             if (POSTPONE) t.node = kNoNode;
@@ -1861,10 +1897,30 @@ struct ScenePtr {
         }
     }
 };
-template <bool COUNT, bool GLOBAL = true>
+// The seven vectors of a Node128 a visit needs, planes picked by the ray's signs (trav_ray_signs): near x / y / z, far x / y / z,
+// children. A uniform base plus a 32-bit byte offset per lane (node * 128 + 0 or 48): global_load with an SGPR base.
+struct WidePlanes {
+    float4 nx, ny, nz, fx, fy, fz, ch;
+};
+DEV WidePlanes load_wide_planes(const float4* wide_nodes, const Trav& t) {
+    const char* nodes = reinterpret_cast<const char*>(wide_nodes); // the wide tree is never staged in LDS
+    auto plane = [&](uint32_t byte_offset) {
+        const f4v v = *(global_f4v*)(nodes + byte_offset);
+        return make_float4(v.x, v.y, v.z, v.w);
+    };
+    const uint32_t base = (uint32_t)t.node << 7;
+    const uint32_t ax = base + t.nx, ay = base + t.ny, az = base + t.nz;
+    return WidePlanes{plane(ax), plane(ay + 16u), plane(az + 32u), plane(ax ^ 48u), plane((ay ^ 48u) + 16u), plane((az ^ 48u) + 32u), plane(base + 96u)};
+}
+template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
 DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node}; // the wide tree is never staged in LDS
-    return wide_node_visit<COUNT>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
+#if PYR_EXPERIMENT_UNSIGNED_GENERIC
+    const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
+    return wide_node_visit<COUNT, POSTPONE>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
+#else
+    const WidePlanes n = load_wide_planes(view.nodes, t);
+    return wide_node_visit<COUNT, POSTPONE, true>(n.nx, n.ny, n.nz, n.fx, n.fy, n.fz, n.ch, t, stack, cnt);
+#endif
 }
 
 // One primitive of a leaf, its record already loaded (a, b, c = the three vectors of a DevPrim): the tests and the
@@ -1953,13 +2009,11 @@ DEV bool trav_step_unified(const SceneView& view, Trav& t, TravStack& stack, Cou
 template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_node_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
     if (view.wide) return trav_step_wide<COUNT, GLOBAL>(view, t, stack, cnt);
-    const ScenePtr<GLOBAL> nd{view.nodes + 4 * t.node};
-    const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
     if (COUNT) cnt.box_tests += 2;
     float e0, e1;
-    slab_pair(n0, n1, n2, t.o, t.inv, e0, e1);
+    int c0, c1;
+    slab_pair_signed<GLOBAL>(view.nodes, (uint32_t)t.node, t.nx >> 1, t.ny >> 1, t.nz >> 1, t.o, t.inv, e0, e1, c0, c1); // 48 -> 24: the binary node's stride
     const bool h0 = (e0 >= 0.0f) & (e0 < t.closest), h1 = (e1 >= 0.0f) & (e1 < t.closest);
-    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
     if (h0 && h1) {
         const bool swap = e1 < e0;
         t.node = swap ? c1 : c0;
@@ -2103,8 +2157,7 @@ DEV bool trav_step_postponed(const SceneView& view, Trav& t, TravStack& stack, C
             }
         }
     } else if (want_node) {
-        const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
-        wide_node_visit<COUNT, true>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
+        trav_step_wide<COUNT, true, true>(view, t, stack, cnt);
     }
     return active && t.node == kNoNode && t.parked == 0;
 }
@@ -2138,6 +2191,9 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
 #endif
 #ifndef PYR_LEAN_STEP
 #define PYR_LEAN_STEP 1
+#endif
+#ifndef PYR_SIGNED_PLANES
+#define PYR_SIGNED_PLANES 1 // the straight-line step picks a node's near / far planes by the ray's signs (trav_ray_signs)
 #endif
 template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
@@ -2178,10 +2234,15 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
     if (n_nodes >= n_leaves) {
         if (active && at_node) {
             const int top = stack.lds[below * BLOCK];
-            const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
             float e[4];
             int c[4];
+#if PYR_SIGNED_PLANES
+            const WidePlanes pl = load_wide_planes(view.nodes, t);
+            wide_node_children<COUNT, true>(pl.nx, pl.ny, pl.nz, pl.fx, pl.fy, pl.fz, pl.ch, t, cnt, e, c);
+#else
+            const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
             wide_node_children<COUNT>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, cnt, e, c);
+#endif
             const bool none = c[0] == INT32_MIN, hit1 = c[1] != INT32_MIN, hit2 = c[2] != INT32_MIN, hit3 = c[3] != INT32_MIN;
             const int n = (hit1 ? 1 : 0) + (hit2 ? 1 : 0) + (hit3 ? 1 : 0); // children to push: c[1 .. n], far to near
             const int above = t.sp + n;
@@ -2825,6 +2886,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
             const unsigned long long prof_t0_3 = clock64();
 #endif
             w.t.inv = box_reciprocal(w.t.d); // 1 / direction for the box tests, live in this phase only
+            trav_ray_signs(w.t);
             if (!LDS_SCENE && PYR_LEAN_STEP && !PYR_POSTPONE_LEAF && view.wide && view.pairs != nullptr) {
                 for (int step = 0; step < trav_steps; ++step) {
                     PROF_LANES(3, w.stage == ST_TRAV);
@@ -3037,6 +3099,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_split(DevSc
                     t.u = t.v = 0.0f;
                     trav_restart(t);
                     t.inv = box_reciprocal(t.d);
+                    trav_ray_signs(t);
                     busy = true;
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -3163,6 +3226,7 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(D
                     const float* r = L.rays + 6 * (size_t)ray;
                     trav_begin<COUNT>(S, t, ld3(r), ld3(r + 3), false, 0.0f, cnt);
                     t.inv = box_reciprocal(t.d);
+                    trav_ray_signs(t);
                     busy = true;
                 }
                 feed.next += min((uint32_t)idle, available);
@@ -3564,6 +3628,7 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void wf_trav_kernel(Dev
                         }
                         trav_restart(t);
                         t.inv = box_reciprocal(t.d);
+                        trav_ray_signs(t);
                         busy = true;
                     }
                 }
@@ -3783,6 +3848,9 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
 using RenderKernel = void (*)(DevScene, RenderLaunch);
 template <bool C, bool I, bool L>
 static RenderKernel pick_tables(bool sm, bool lds_tables) {
+#ifdef PYR_DEV_ONLY_SM // developer builds for reading the ISA (tools/asm_sm.sh): only the kernel the BASELINE meshes run is instantiated
+    return render_kernel_sm<false, false, false, true>;
+#endif
     if (sm) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
     return lds_tables ? render_kernel<C, I, L, true> : render_kernel<C, I, L, false>;
 }
