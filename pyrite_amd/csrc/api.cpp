@@ -536,6 +536,12 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     }
     v.needs_interpreter = needs_interpreter ? 1u : 0u;
     v.uses_textures = uses_textures ? 1u : 0u;
+    v.hero_only_records = 0;
+    for (uint32_t i = 0; i < d->num_materials; ++i)
+        for (uint32_t k = 0; k < d->materials[i].num_emissive; ++k) {
+            const int probability = d->components[d->materials[i].first_emissive + k].probability_program;
+            if (probability >= 0 && programs[(size_t)probability].reads_wavelength) v.hero_only_records = 1u;
+        }
     v.tri_tex = (const float*)s->tri_tex.ptr;
     v.sphere_tex_scale = (const float*)s->sphere_tex_scale.ptr;
     v.plane_frames = (const float*)s->plane_frames.ptr;

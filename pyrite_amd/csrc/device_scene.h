@@ -111,6 +111,9 @@ struct DevScene {
     const DevTexture* textures;
     const float* texture_data;
     uint32_t uses_textures; // some program holds a texture opcode or some material a normal map
+    // some emissive component's probability program reads the wavelength: a light sample of such a material is added for the hero
+    // wavelength only (algorithm.rs:78), i.e. the spectral tape can hold hero-only records. No BASELINE scene has one.
+    uint32_t hero_only_records;
 };
 
 constexpr uint32_t kMaxStackDepth = 64; // >= kMaxBvhDepth (bvh.h) and >= the wide tree's stack need (else the binary tree is walked)

@@ -2220,12 +2220,15 @@ DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Count
 template <bool COUNT>
 DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
     const bool at_node = t.node >= 0;
-    const unsigned long long nodes = ballot64(active && at_node), leaves = ballot64(active && !at_node);
+    // ballots of single comparisons, combined as scalars: the ballot of a conjunction is lowered through a v_cndmask 0 / 1 and a
+    // v_cmp_ne (two vector instructions per ballot, three ballots per step)
+    const unsigned long long with_ray = ballot64(active), at_nodes = ballot64(at_node);
+    const unsigned long long nodes = with_ray & at_nodes, leaves = with_ray & ~at_nodes;
     // the counts as 32-bit scalars the compiler cannot see through: left alone it compares the two 64-bit population counts,
     // for which the scalar unit has no instruction -- two v_mov and a v_cmp_lt_u64 per step
     int n_nodes = __builtin_popcountll(nodes), n_leaves = __builtin_popcountll(leaves);
     asm volatile("" : "+s"(n_nodes), "+s"(n_leaves));
-    if (ballot64(active && t.sp + 3 > stack.lds_entries) != 0ull) { // somebody's stack is about to leave LDS: the generic step
+    if ((with_ray & ballot64(t.sp + 3 > stack.lds_entries)) != 0ull) { // somebody's stack is about to leave LDS: the generic step
         if (n_nodes >= n_leaves) return (active && at_node) ? trav_node_step<COUNT, true>(view, t, stack, cnt) : false;
         return (active && !at_node) ? trav_leaf_step<COUNT, true>(view, t, stack, cnt) : false;
     }
@@ -2652,6 +2655,11 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     // the lane it replays with a cross-lane read. (Reading record after record of one column from the item's lane was a chain
     // of dependent HBM round trips: it took a quarter of the render.) Lanes that are not being replayed load nothing.
     const unsigned long long* my_column = L.tape + tape_column;
+    // Rows past the end of a tape read as the identity record of the eager form -- "reflectance *= value[one] * 1.0", and
+    // x * 1.0 is x bit for bit -- so the straight-line replay needs no "is this row still on my tape" test per record.
+    const bool eager_form = n_spectral != 0;
+    const unsigned long long past_the_end =
+        eager_form ? ((unsigned long long)(kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT) | ((unsigned long long)__float_as_uint(1.0f) << 32)) : 0ull;
 #ifndef PYR_REPLAY_ROWS
 #define PYR_REPLAY_ROWS 8
 #endif
@@ -2697,7 +2705,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
             unsigned long long rows[ROWS];
 #pragma unroll
-            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < my_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : 0ull;
+            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < my_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : past_the_end;
             // all cross-lane reads of the batch first (one wait), then, in the eager form, all value reads (one more)
             uint32_t words[ROWS];
             float factors[ROWS];
@@ -2710,13 +2718,24 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 float values[ROWS];
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) values[j] = spectral_values[words[j] & TAPE_EAGER_SLOT_MASK]; // slot << 8 is slot * BLOCK
+                if (S.hero_only_records == 0) { // (uniform) no record of this scene is for the hero alone: every record applies
+#pragma unroll
+                    for (uint32_t j = 0; j < ROWS; ++j) {
+                        const float m = values[j] * factors[j];
+                        const bool adds = (int)words[j] < 0;
+                        const float multiplied = refl * m, added = bright + multiplied; // m * refl is refl * m
+                        bright = adds ? added : bright;
+                        refl = adds ? refl : multiplied;
+                    }
+                    continue;
+                }
                 const uint32_t not_for_me = hero ? 0u : TAPE_HERO_ONLY; // a hero-only record is skipped by the companions
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) {
                     const float m = values[j] * factors[j];
-                    const bool apply = run & (r0 + j < ops) & ((words[j] & not_for_me) == 0u);
+                    const bool apply = (words[j] & not_for_me) == 0u;
                     const bool adds = (int)words[j] < 0;
-                    const float multiplied = refl * m, added = bright + m * refl;
+                    const float multiplied = refl * m, added = bright + multiplied;
                     bright = (apply & adds) ? added : bright;
                     refl = (apply & !adds) ? multiplied : refl;
                 }
