@@ -2686,20 +2686,43 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         // the value (and apply the program's constant factor, the same multiplication run_program makes).
         const bool eager = n_spectral != 0;
         if (eager) {
+            // Spectrum::get (project/spectra.rs:32-55) of every slot at this item's wavelength, the operations of spectrum_eval.
+            // Array spectra over the same grid (min, max, count: C3's three wall colours) share the index arithmetic -- one
+            // division instead of three; the look-ups themselves are straight-line (the clamped ends are selects).
             const uint32_t* slot_program = prepared_lds + 8 * L.tape_programs_lds;
+            uint32_t grid_min = 0, grid_max = 0, grid_count = 0; // the grid i0 / mix / below / above belong to (count 0: none yet)
+            uint32_t i0 = 0;
+            float mix = 0.0f;
+            bool below = false, above = false;
             for (uint32_t slot = 0; slot < n_spectral; ++slot) {
                 const uint32_t* e = prepared_lds + 8 * slot_program[slot];
-                Prepared q_prog;
-                q_prog.mode = e[0], q_prog.c = __uint_as_float(e[1]);
-                q_prog.sp.format = e[2], q_prog.sp.min = __uint_as_float(e[3]), q_prog.sp.max = __uint_as_float(e[4]), q_prog.sp.offset = e[5], q_prog.sp.count = e[6];
-                q_prog.data = S.spectrum_data + e[5];
-                q_prog.id = slot_program[slot];
-                VmInput in{wl, mk(0, 0, 0), mk(0, 0, 0)};
+                const uint32_t mode = e[0], format = e[2], count = e[6];
+                const float c = __uint_as_float(e[1]);
+                const float* data = S.spectrum_data + e[5];
+                float v;
 #ifdef PYR_REPLAY_NOEAGER_EVAL // timing ablation (the film is wrong): what the per-item look-ups of the spectrum-reading programs cost
-                spectral_values[slot * BLOCK] = in.wavelength * 1.0e-3f;
+                v = wl * 1.0e-3f;
 #else
-                spectral_values[slot * BLOCK] = eval_prepared<false>(S, q_prog, in);
+                if (format == PYR_SPECTRUM_ARRAY && count != 0u) {
+                    if (e[3] != grid_min || e[4] != grid_max || count != grid_count) { // (uniform) another grid than the previous slot's
+                        grid_min = e[3], grid_max = e[4], grid_count = count;
+                        const float lo = __uint_as_float(grid_min), hi = __uint_as_float(grid_max);
+                        below = wl <= lo, above = wl >= hi;
+                        const float normalized = (wl - lo) / (hi - lo);
+                        const float float_index = normalized * ((float)count - 1.0f);
+                        const float min_float_index = truncf(float_index);
+                        i0 = (below | above) ? 0u : (uint32_t)min_float_index;
+                        mix = float_index - min_float_index;
+                    }
+                    const float inside = data[i0] * (1.0f - mix) + data[i0 + 1] * mix;
+                    v = below ? data[0] : (above ? data[count - 1] : inside);
+                } else {
+                    PyrSpectrum sp;
+                    sp.format = format, sp.min = __uint_as_float(e[3]), sp.max = __uint_as_float(e[4]), sp.offset = e[5], sp.count = count;
+                    v = spectrum_eval(sp, data, wl);
+                }
 #endif
+                spectral_values[slot * BLOCK] = mode == FAST_SPECTRUM ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
             }
         }
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
@@ -2799,17 +2822,34 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 // spectrum-reading programs when they fit the kTapeEagerSlots value rows (the replay then looks each up once per item), else
 // 0 (looked up record by record). Called by every thread of the workgroup; ends with a barrier.
 DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const RenderLaunch& L, uint32_t* prepared_lds) {
+    // Programs that evaluate alike -- the same shape, factor and spectrum (a scene compiles one colour program per use: C3's
+    // three white walls are three programs over one spectrum) -- share a value slot: the replay looks a slot up once per item.
     auto reads_spectrum = [&](uint32_t i) { return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && S0.programs[i].fast != FAST_NONE; };
+    auto alike = [&](uint32_t i, uint32_t j) {
+        const DevProgram &a = S0.programs[i], &b = S0.programs[j];
+        return a.fast == b.fast && __float_as_uint(a.fast_scale) == __float_as_uint(b.fast_scale) && a.fast_spectrum == b.fast_spectrum;
+    };
+    auto first_alike = [&](uint32_t i) { // the first spectrum-reading program that evaluates like program i
+        for (uint32_t j = 0; j < i; ++j)
+            if (reads_spectrum(j) && alike(i, j)) return j;
+        return i;
+    };
+    auto slot_of = [&](uint32_t representative) { // its rank among the representatives
+        uint32_t slot = 0;
+        for (uint32_t j = 0; j < representative; ++j) slot += (reads_spectrum(j) && first_alike(j) == j) ? 1u : 0u;
+        return slot;
+    };
     uint32_t n_spectral = 0;
-    for (uint32_t i = 0; i < L.tape_programs_lds; ++i) n_spectral += reads_spectrum(i) ? 1u : 0u;
+    for (uint32_t i = 0; i < L.tape_programs_lds; ++i) n_spectral += (reads_spectrum(i) && first_alike(i) == i) ? 1u : 0u;
     for (uint32_t i = threadIdx.x; i < L.tape_programs_lds; i += BLOCK) {
         const Prepared q = prepare_program<false>(S, i);
-        uint32_t slot = 0;
-        for (uint32_t j = 0; j < i; ++j) slot += reads_spectrum(j) ? 1u : 0u;
+        const bool spectral = reads_spectrum(i);
+        const uint32_t representative = spectral ? first_alike(i) : i;
+        const uint32_t slot = spectral ? slot_of(representative) : 0u;
         uint32_t* e = prepared_lds + 8 * i;
         e[0] = q.mode, e[1] = __float_as_uint(q.c), e[2] = q.sp.format, e[3] = __float_as_uint(q.sp.min), e[4] = __float_as_uint(q.sp.max);
         e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = slot;
-        if (reads_spectrum(i) && slot < kTapeOneSlot) prepared_lds[8 * L.tape_programs_lds + slot] = i;
+        if (spectral && representative == i && slot < kTapeOneSlot) prepared_lds[8 * L.tape_programs_lds + slot] = i;
     }
     __syncthreads();
     return n_spectral > kTapeOneSlot ? 0u : n_spectral; // too many for the reserved rows (the last one holds 1.0): the replay looks them up record by record
