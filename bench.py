@@ -26,8 +26,13 @@ Extra objects on the line:
                 printed because the algorithmic figure rewards wasted tests: a better tree lowers both it and `achieved`.
   c2            (N = 1, default workload only) configs[1], the 36-triangle Cornell box at 1024^2 x 256 spp, three steps: its
                 scene lives in LDS, so its algorithmic bytes are LDS reads and the object says "bound": "lds".
-  cpu_baseline  the CPU oracle (oracle/liboracle.so, a port of the reference's algorithm -- the Rust reference cannot be
-                built here) timed on this host's cores, rank 0, N = 1 only, on a bounded sample of the same workload.
+  c5            (N = 1, default workload only) configs[4]'s workload on one GPU: the same mesh made of dispersive glass, 20
+                bounces, ONE timed step at the full 4096 spp (~20 s) after a warm-up at reduced spp, with its own roofline.
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm -- the Rust reference cannot be built here) rebuilt on
+                this host with -O3 -march=native (oracle/Makefile `native`; the reference builds with target-cpu=native,
+                .cargo/config:2) and timed on as many threads as the process may really use (the smaller of its CPU affinity,
+                the host's physical cores and its cgroup CPU quota), rank 0, N = 1 only, on a bounded sample of the same
+                workload. The line carries the CPU model, the core counts and a thread-scaling table.
 """
 import argparse
 import json
@@ -53,15 +58,75 @@ def algorithmic_bytes(counters):
     return sum(BYTES[k] * counters[k] for k in BYTES)
 
 
+def host_cpu():
+    """What this process may really use: CPU model, logical / physical core counts, affinity, cgroup CPU quota."""
+    model, cores = "unknown", set()
+    try:
+        physical, core = None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "model name":
+                    model = val
+                elif key == "physical id":
+                    physical = val
+                elif key == "core id":
+                    core = val
+                elif not key and physical is not None and core is not None:
+                    cores.add((physical, core))
+                    physical = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota us> <period us>" or "max <period>"
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    physical_cores = len(cores) or logical
+    usable = max(1, min(affinity, physical_cores, int(quota) if quota and quota >= 1 else affinity))
+    return {"model": model, "logical_cpus": logical, "physical_cores": physical_cores, "affinity": affinity,
+            "cgroup_cpu_quota": round(quota, 2) if quota else None, "threads_used": usable}
+
+
+def native_oracle():
+    """oracle/liboracle_native.so: the oracle rebuilt on THIS host with -O3 -march=native (the portable build the tests use is
+    -O2 -march=x86-64-v3). Falls back to the portable library, and says so, when the host has no compiler."""
+    import subprocess
+
+    native = os.path.join(ROOT, "oracle", "liboracle_native.so")
+    try:
+        # -B: always rebuilt -- a copy built with another host's -march=native must never be loaded here
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return native, "-O3 -march=native -ffp-contract=off, built on this host"
+    except (OSError, subprocess.CalledProcessError):
+        return None, "-O2 -march=x86-64-v3 -ffp-contract=off (portable build: this host could not rebuild the oracle)"
+
+
 def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
-    """Time the oracle on the same scene and image with fewer samples per pixel (the loop is linear in spp, simple.rs:73).
-    Also reports how the port scales with threads (1 / 32 / all) on a few tiles, so the figure can be judged."""
+    """Time the oracle on the same scene and image with fewer samples per pixel (the loop is linear in spp, simple.rs:73), on
+    as many threads as this process may really use, with a thread-scaling table (>= 2 s per point) so the figure can be judged."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import copy
 
     import oracle
 
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    path, flags = native_oracle()
+    if path:
+        oracle.use_library(path)
+    cpu = host_cpu()
+    threads = cpu["threads_used"]
     t0 = time.perf_counter()
     sc = oracle.OracleScene(world)
     build_s = time.perf_counter() - t0
@@ -69,18 +134,23 @@ def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
     r.pixel_samples = 1
     tiles = renderer.num_tiles(width, height)
 
-    def rate(n_threads, n_tiles):
-        a = max(0, tiles // 2 - n_tiles // 2)
-        film = renderer.new_film(width, height)
-        t = time.perf_counter()
-        c = sc.render(r, cam, film, threads=n_threads, tile_range=(a, min(tiles, a + n_tiles)))
-        return c["samples"] / max(time.perf_counter() - t, 1e-6)
+    def rate(n_threads, seconds):
+        """Msamples/s of `n_threads` on tiles from the middle of the image, for about `seconds`."""
+        n_tiles, done, spent = max(4, 2 * n_threads), 0, 0.0
+        while spent < seconds:
+            a = max(0, tiles // 2 - n_tiles // 2)
+            film = renderer.new_film(width, height)
+            t = time.perf_counter()
+            c = sc.render(r, cam, film, threads=n_threads, tile_range=(a, min(tiles, a + n_tiles)))
+            dt = time.perf_counter() - t
+            done, spent = done + c["samples"], spent + dt
+            n_tiles = min(tiles, int(n_tiles * max(1.5, min(8.0, 1.2 * (seconds - spent) / max(dt, 1e-3)))))
+            if n_tiles >= tiles:
+                break
+        return done / max(spent, 1e-6) / 1e6
 
-    scaling = {}
-    for n in sorted({1, min(32, threads), min(128, threads), threads}):
-        scaling[str(n)] = round(rate(n, min(tiles, 4 * n)) / 1e6, 4)
-    # the figure of record uses the thread count that did best in the probe (more threads than that only add contention)
-    threads = int(max(scaling, key=lambda k: scaling[k]))
+    points = sorted({1, 2, 4, 8, 16, 32, threads} & set(range(1, threads + 1)) | {threads})
+    scaling = {str(n): round(rate(n, 2.0), 4) for n in points}
     spp = int(max(1, min(renderer.pixel_samples, round(scaling[str(threads)] * 1e6 * target_seconds / (width * height)))))
     r.pixel_samples = spp
     film = renderer.new_film(width, height)
@@ -95,6 +165,9 @@ def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
         "kind": "port",
         "sample": "same scene and %dx%d image at %d spp of %d (all tiles), %.1f s of CPU work (+ %.1f s BVH build, not counted)"
                   % (width, height, spp, renderer.pixel_samples, dt, build_s),
+        "build": flags,
+        "host": cpu,
+        "threads_note": "threads = min(CPU affinity, physical cores, cgroup CPU quota): more threads than the quota only get throttled",
         "thread_scaling_Msamples_per_s": scaling,
     }
 
@@ -124,7 +197,9 @@ def traversal_roofline(device_index, n_rays=16_000_000):
     info = world.bvh_info(device_index)
     world.close()
     return {
-        "kernel": "intersect_kernel<false>", "scene": "C3 mesh (819,212 triangles, %d nodes of 64 B)" % info["num_nodes"],
+        "kernel": "intersect_kernel<false>",
+        "scene": "C3 mesh (819,212 triangles): %d four-child nodes of 128 B + %d two-triangle records of 80 B = %.1f MB walked"
+                 % (info["num_wide_nodes"], info["num_pair_records"], (info["wide_node_bytes"] + info["pair_record_bytes"]) / 1e6),
         "rays": n_rays, "ray_kind": "incoherent (uniform origins and directions)", "kernel_ms": round(best, 3),
         "Mrays_per_s": round(n_rays / best / 1e3, 1), "box_tests_per_ray": round(counters["box_tests"] / n_rays, 2),
         "triangle_tests_per_ray": round(counters["triangle_tests"] / n_rays, 2), "bound": "hbm", "achieved": round(achieved, 1),
@@ -133,14 +208,16 @@ def traversal_roofline(device_index, n_rays=16_000_000):
 
 
 def load_traffic(workload):
+    """PMC traffic of the workload's full single-GPU launch from the committed rocprofv3 --pmc passes: (bytes per launch, the
+    kernel time of those passes, where they came from). Not a measurement of this run -- the line says so (`traffic_source`)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         with open(path) as f:
             table = json.load(f)
         entry = table.get(workload)
         if entry:
-            return entry.get("hbm_bytes_per_launch"), entry.get("kernel_ms")
-    return None, None
+            return entry.get("hbm_bytes_per_launch"), entry.get("kernel_ms"), "profiles/traffic.json: " + entry.get("source", "rocprofv3 --pmc")
+    return None, None, None
 
 
 class Workload:
@@ -239,9 +316,14 @@ class Workload:
         traversal = 32 * counters["box_tests"] + 36 * counters["triangle_tests"] + 16 * (counters["sphere_tests"] + counters["plane_tests"])
         total = algorithmic_bytes(counters)
         achieved = total / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_ms = load_traffic(self.name)
+        traffic, traffic_ms, traffic_source = load_traffic(self.name)
         if self.reduced or self.world_size != 1:
             traffic = traffic_ms = None  # the committed counters are for the full single-GPU launch
+            traffic_source = None
+        elif traffic is not None and traffic_ms and abs(traffic_ms - kernel_ms) > 0.02 * kernel_ms:
+            # the kernel the counters were collected on took another time than this run's: not the same build any more
+            traffic_source = "dropped: %s took %.1f ms per launch, this run %.1f ms" % (traffic_source, traffic_ms, kernel_ms)
+            traffic = traffic_ms = None
         out = {
             "bound": "lds" if self.lds_resident else "hbm",
             "achieved": round(achieved, 1),
@@ -249,6 +331,7 @@ class Workload:
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "measured_hbm_GBps": round(traffic / ((traffic_ms or kernel_ms) * 1e-3) / 1e9, 1) if traffic else None,
             "compared_with_target": "frac = algorithmic bytes / kernel time / 8 TB/s is what north_star's >= 0.40 is compared with",
             "kernel": self.kernel_name(),
@@ -325,6 +408,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traversal", action="store_true", help="skip the BVH-traversal roofline measurement on the C3 scene")
     ap.add_argument("--no-c2", action="store_true", help="skip the extra C2 (configs[1]) measurement")
+    ap.add_argument("--no-c5", action="store_true", help="skip the extra C5 (configs[4]'s workload on one GPU) measurement")
     ap.add_argument("--dev", default="", help="development overrides, e.g. spectrum_samples=1,light_samples=0,bounces=2 (marks the line reduced)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -438,6 +522,26 @@ def main():
                           "ms_per_step": round(c2_ms, 3), "config": c2_config,
                           "roofline": c2.roofline(c2.counters_for_seeds(c2_seeds), c2_kernel_ms, 1)}
             c2.world.close()
+        if world_size == 1 and args.workload == "C3" and not args.no_c5 and not wl.reduced:
+            # configs[4]'s workload beside the headline: the glass mesh, 20 bounces -- a warm-up at 64 spp, then ONE timed step at
+            # the full 4096 spp and its counters pass
+            warm_args = argparse.Namespace(**{**vars(args), "spp": 64, "dev": ""})
+            c5_warm = Workload("C5", warm_args, torch, local_rank, 1, False)
+            c5_warm.step()
+            fence()
+            c5_warm.world.close()
+            del c5_warm
+            c5_args = argparse.Namespace(**{**vars(args), "spp": None, "dev": ""})
+            c5 = Workload("C5", c5_args, torch, local_rank, 1, False)
+            c5_ms, c5_film, c5_seeds = timed_steps(c5, 1, 0, args.seed, fence, dist, 1)
+            c5_kernel_ms = sum(a.elapsed_time(b) for a, b in c5.launch_events)
+            c5_config = c5.describe(1, float(c5_film[..., 1].sum(dtype=torch.float64).item()))
+            mismatch = mismatch or c5_config["film_weight_check"] != "ok"
+            del c5_film
+            line["c5"] = {"value": round(c5.width * c5.height * c5.spp / (c5_ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "steps": 1, "warmup": "1 at 64 spp",
+                          "ms_per_step": round(c5_ms, 3), "config": c5_config, "roofline": c5.roofline(c5.counters_for_seeds(c5_seeds), c5_kernel_ms, 1)}
+            c5.world.close()
+            del c5
         if world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl.world, wl.cam, wl.renderer, wl.width, wl.height)
         print(json.dumps(line), flush=True)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PYR_ABI_VERSION 3
+#define PYR_ABI_VERSION 4
 
 typedef enum PyrStatus {
     PYR_OK = 0,
@@ -385,6 +385,12 @@ typedef struct PyrBvhInfo {
     uint32_t num_primitives;
     uint64_t node_bytes;
     uint64_t primitive_bytes;
+    /* ABI 4: the tree the resumable traversal walks on scenes that do not live in LDS (0 when the scene has none): 128-byte
+     * four-child nodes; for triangle-only scenes a second copy of them whose leaves index 80-byte records of two triangles */
+    uint32_t num_wide_nodes;
+    uint32_t num_pair_records;
+    uint64_t wide_node_bytes;
+    uint64_t pair_record_bytes;
 } PyrBvhInfo;
 int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out);
 

@@ -2,7 +2,7 @@
 tests/test_abi.py checks sizes and that every declared symbol is exported."""
 import ctypes as C
 
-PYR_ABI_VERSION = 3
+PYR_ABI_VERSION = 4
 
 PYR_OK = 0
 PYR_ERR_INVALID_ARGUMENT = -1
@@ -218,6 +218,10 @@ class PyrBvhInfo(C.Structure):
         ("num_primitives", C.c_uint32),
         ("node_bytes", C.c_uint64),
         ("primitive_bytes", C.c_uint64),
+        ("num_wide_nodes", C.c_uint32),
+        ("num_pair_records", C.c_uint32),
+        ("wide_node_bytes", C.c_uint64),
+        ("pair_record_bytes", C.c_uint64),
     ]
 
 

@@ -294,7 +294,12 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         b.shape = ((uint32_t)PYR_SHAPE_TRIANGLE << 30) | i;
         bounds.push_back(b);
     }
-    BuiltBvh bvh = build_bvh(bounds);
+    // Leaves are tested in pairs only by the four-child pair tree: a triangle-only scene too big to live in LDS (its
+    // primitives alone outgrow the 8 KB the LDS-resident walk allows) with neither tree switched off.
+    const char* wide_switch = std::getenv("PYRITE_WIDE_BVH");
+    const char* pair_switch = std::getenv("PYRITE_PAIR_PRIMS");
+    const bool pair_tree_expected = d->num_spheres == 0 && bounds.size() * 48 > 8 * 1024 && !(wide_switch && wide_switch[0] == '0') && !(pair_switch && pair_switch[0] == '0');
+    BuiltBvh bvh = build_bvh(bounds, pair_tree_expected);
     if (bvh.max_depth > 96) return fail(PYR_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack allows");
 
     std::vector<DevPrim> prims(bvh.prim_order.size());
@@ -554,6 +559,10 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     s->info.num_primitives = (uint32_t)prims.size();
     s->info.node_bytes = bvh.nodes.size() * sizeof(Node64);
     s->info.primitive_bytes = prims.size() * sizeof(DevPrim);
+    s->info.num_wide_nodes = (uint32_t)wide.nodes.size();
+    s->info.num_pair_records = (uint32_t)pairs.size();
+    s->info.wide_node_bytes = wide.nodes.size() * sizeof(Node128);
+    s->info.pair_record_bytes = pairs.size() * sizeof(DevPrimPair);
     return PYR_OK;
 }
 

@@ -48,7 +48,7 @@ inline uint32_t ceil_log2(uint32_t n) {
 
 } // namespace
 
-BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
+BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, bool leaves_tested_in_pairs) {
     BuiltBvh out;
     const uint32_t n = (uint32_t)prims.size();
     std::vector<Ref> refs(n);
@@ -114,7 +114,8 @@ BuiltBvh build_bvh(const std::vector<PrimBounds>& prims) {
 
     // What testing n primitives of one leaf costs, in primitive tests. PYR_SAH_PAIRS=1: the render kernels test a leaf's
     // triangles two per step (DevPrimPair), so an odd triangle costs a whole step.
-    auto leaf_tests = [](uint32_t count) { return PYR_SAH_PAIRS ? (float)((count + 1u) & ~1u) : (float)count; };
+    const bool in_pairs = PYR_SAH_PAIRS && leaves_tested_in_pairs;
+    auto leaf_tests = [in_pairs](uint32_t count) { return in_pairs ? (float)((count + 1u) & ~1u) : (float)count; };
     // Splits [begin,end) and returns mid; false when the range should become a leaf.
     auto split = [&](uint32_t begin, uint32_t end, uint32_t depth, const Box& box, const Box& cbox, uint32_t& mid) -> bool {
         uint32_t count = end - begin;

@@ -57,7 +57,10 @@ constexpr float kSahNodeCost = PYR_SAH_NODE_COST; // cost of one node visit in u
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return -1 - (int32_t)((first << 3) | count); }
 
-BuiltBvh build_bvh(const std::vector<PrimBounds>& prims);
+// `leaves_tested_in_pairs`: the tree's leaves will be tested two triangles per step (the four-child pair tree of a
+// triangle-only scene that does not live in LDS), so the SAH counts a leaf of n primitives as n rounded up to even -- only
+// when PYR_SAH_PAIRS is on; everything else (sphere scenes, LDS-resident scenes, the binary walk) counts singly.
+BuiltBvh build_bvh(const std::vector<PrimBounds>& prims, bool leaves_tested_in_pairs = false);
 
 // Four-child node, 128 bytes = one L2 line, read as eight float4: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] child[4]
 // pad[4]. Built by collapsing the binary tree (the child with the largest surface area is replaced by its own two children

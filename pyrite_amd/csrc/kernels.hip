@@ -2044,7 +2044,7 @@ DEV bool leaf_pair_test(const float4 q0, const float4 q1, const float4 q2, const
     const f2v e1x = {q2.x, q2.y}, e1y = {q2.z, q2.w}, e1z = {q3.x, q3.y};
     const f2v e2x = {q3.z, q3.w}, e2y = {q4.x, q4.y}, e2z = {q4.z, q4.w};
     const uint32_t shape_a = __float_as_uint(q1.z), shape_b = __float_as_uint(q1.w);
-    if (COUNT) cnt.triangle_tests += count >= 2u ? 2u : 1u;
+    if (COUNT) cnt.triangle_tests += count >= 2u ? 2u : (count != 0u ? 1u : 0u); // an empty leaf's record holds no triangle
     const f2v dx = {t.d.x, t.d.x}, dy = {t.d.y, t.d.y}, dz = {t.d.z, t.d.z};
     const f2v ox = {t.o.x, t.o.x}, oy = {t.o.y, t.o.y}, oz = {t.o.z, t.o.z};
     // triangle_test, shapes/mod.rs:75-119, for both triangles: p = d x e2, det = e1 . p, t = o - v1, u = (t . p) / det,

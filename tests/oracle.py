@@ -18,13 +18,23 @@ F3 = C.c_float * 3
 F6 = C.c_float * 6
 
 
+_lib_path = None
+
+
+def use_library(path):
+    """Load another build of the oracle (bench.py: oracle/liboracle_native.so) instead of the portable one. Before first use."""
+    global _lib_path
+    assert _lib is None, "the oracle library is already loaded"
+    _lib_path = path
+
+
 def lib():
     global _lib
     if _lib is None:
         src = os.path.join(ORACLE_DIR, "oracle.cpp")
-        if not os.path.exists(LIB) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB)):
+        if _lib_path is None and (not os.path.exists(LIB) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB))):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
-        L = C.CDLL(LIB)
+        L = C.CDLL(_lib_path or LIB)
         L.oracle_last_error.restype = C.c_char_p
         L.oracle_scene_create.argtypes = [C.POINTER(abi.PyrSceneDesc), C.POINTER(C.c_void_p)]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
