@@ -10,7 +10,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 OUT = os.path.join(CSRC, "libpyrite_gpu.so")
 SOURCES = ["kernels.hip", "api.cpp", "multi.cpp", "bvh.cpp"]
-HEADERS = ["bvh.h", "device_scene.h", "api_internal.h", os.path.join("..", "..", "include", "pyrite_gpu.h")]
+HEADERS = ["bvh.h", "device_scene.h", "api_internal.h", "exact_math.h", os.path.join("..", "..", "include", "pyrite_gpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",

@@ -25,6 +25,7 @@
 #include <string>
 
 #include "device_scene.h"
+#include "exact_math.h"
 
 namespace pyr {
 
@@ -57,7 +58,7 @@ DEV f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
 DEV f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DEV float magnitude(f3 a) { return sqrtf(dot(a, a)); }
+DEV float magnitude(f3 a) { return sqrt32(dot(a, a)); }
 DEV f3 normalize_to(f3 a, float m) { return a * (m / magnitude(a)); } // cgmath: v * (m / |v|)
 DEV f3 normalize(f3 a) { return normalize_to(a, 1.0f); }
 DEV f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
@@ -121,7 +122,7 @@ DEV float asin32_core(float a) { // asin(a) for 0 <= a <= 1
     const bool big = a > 0.5f;
     if (big) {
         z = 0.5f * (1.0f - a);
-        x = sqrtf(z);
+        x = sqrt32(z);
     } else {
         x = a;
         z = x * x;
@@ -134,8 +135,8 @@ DEV float asin32_core(float a) { // asin(a) for 0 <= a <= 1
     return r;
 }
 DEV float acos32(float x) {
-    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asin32_core(sqrtf(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * asin32_core(sqrtf(0.5f * (1.0f - x)));
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asin32_core(sqrt32(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asin32_core(sqrt32(0.5f * (1.0f - x)));
     float a = asin32_core(fabsf(x));
     return 1.5707963267948966f - (x < 0.0f ? -a : a);
 }
@@ -267,7 +268,7 @@ DEV float schlick(float n1, float n2, f3 normal, f3 incident) {
         float n = n1 / n2;
         float sin_t2 = n * n * (1.0f - cos_psi * cos_psi);
         if (sin_t2 > 1.0f) return 1.0f;
-        cos_psi = sqrtf(1.0f - sin_t2);
+        cos_psi = sqrt32(1.0f - sin_t2);
     }
     float inv_cos = 1.0f - cos_psi;
     return r0 * r0 + (1.0f - r0 * r0) * inv_cos * inv_cos * inv_cos * inv_cos * inv_cos;
@@ -596,7 +597,7 @@ DEV f3 sample_cone(Rng& rng, f3 direction, float cos_half) { // math.rs:125-137
     f3 o2 = normalize(cross(direction, o1));
     float r1 = PI_F * 2.0f * rng_f32(rng);
     float r2 = cos_half + (1.0f - cos_half) * rng_f32(rng);
-    float oneminus = sqrtf(1.0f - r2 * r2);
+    float oneminus = sqrt32(1.0f - r2 * r2);
     return o1 * cos32(r1) * oneminus + o2 * sin32(r1) * oneminus + direction * r2;
 }
 DEV float solid_angle(float cos_half) { return cos_half >= 1.0f ? 0.0f : 2.0f * PI_F * (1.0f - cos_half); } // :139-145
@@ -643,7 +644,7 @@ DEV bool sphere_test(f3 center, float radius, f3 o, f3 d, float& dist, f3& point
     if (tca < 0.0f) return false;
     float d2 = dot(l, l) - tca * tca;
     if (d2 > radius * radius) return false;
-    float thc = sqrtf(radius * radius - d2);
+    float thc = sqrt32(radius * radius - d2);
     point = o + d * (tca - thc);
     dist = magnitude(point - o);
     return true;
@@ -911,7 +912,7 @@ struct Quat {
 DEV Quat quat_scale(Quat q, float f) { return Quat{q.s * f, q.x * f, q.y * f, q.z * f}; }
 DEV Quat quat_add(Quat a, Quat b) { return Quat{a.s + b.s, a.x + b.x, a.y + b.y, a.z + b.z}; }
 DEV Quat quat_normalize(Quat q) {
-    float m = sqrtf(q.s * q.s + q.x * q.x + q.y * q.y + q.z * q.z);
+    float m = sqrt32(q.s * q.s + q.x * q.x + q.y * q.y + q.z * q.z);
     return quat_scale(q, 1.0f / m);
 }
 DEV Quat quat_conjugate(Quat q) { return Quat{q.s, -q.x, -q.y, -q.z}; }
@@ -924,22 +925,22 @@ DEV Quat quat_from_cols(f3 c0, f3 c1, f3 c2) {
     const float m00 = c0.x, m01 = c0.y, m02 = c0.z, m10 = c1.x, m11 = c1.y, m12 = c1.z, m20 = c2.x, m21 = c2.y, m22 = c2.z;
     float trace = m00 + m11 + m22;
     if (trace >= 0.0f) {
-        float s = sqrtf(1.0f + trace);
+        float s = sqrt32(1.0f + trace);
         float w = 0.5f * s;
         s = 0.5f / s;
         return Quat{w, (m12 - m21) * s, (m20 - m02) * s, (m01 - m10) * s};
     } else if (m00 > m11 && m00 > m22) {
-        float s = sqrtf((m00 - m11 - m22) + 1.0f);
+        float s = sqrt32((m00 - m11 - m22) + 1.0f);
         float x = 0.5f * s;
         s = 0.5f / s;
         return Quat{(m12 - m21) * s, x, (m10 + m01) * s, (m02 + m20) * s};
     } else if (m11 > m22) {
-        float s = sqrtf((m11 - m00 - m22) + 1.0f);
+        float s = sqrt32((m11 - m00 - m22) + 1.0f);
         float y = 0.5f * s;
         s = 0.5f / s;
         return Quat{(m20 - m02) * s, (m10 + m01) * s, y, (m21 + m12) * s};
     } else {
-        float s = sqrtf((m22 - m00 - m11) + 1.0f);
+        float s = sqrt32((m22 - m00 - m11) + 1.0f);
         float z = 0.5f * s;
         s = 0.5f / s;
         return Quat{(m01 - m10) * s, (m02 + m20) * s, (m21 + m12) * s, z};
@@ -1034,7 +1035,7 @@ DEV void refract(float ior, float env_ior, f3 in_direction, f3 normal, Rng& rng,
         prob = 1.0f;
         return;
     }
-    float s = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t));
+    float s = (into ? 1.0f : -1.0f) * (ddn * nnt + sqrt32(cos2t));
     f3 tdir = normalize(in_direction * nnt - normal * s);
     float a = ior - env_ior, b = ior + env_ior;
     float r0 = a * a / (b * b);
@@ -1091,7 +1092,7 @@ DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
         f3 position;
         float distance;
         if (dist2 > radius * radius) {
-            float cos_theta_max = sqrtf(fmaxf(1.0f - (radius * radius) / dist2, 0.0f));
+            float cos_theta_max = sqrt32(fmaxf(1.0f - (radius * radius) / dist2, 0.0f));
             f3 ray_dir = sample_cone(rng, normalize(dir), cos_theta_max);
             if (!sphere_test(center, full_radius, target, ray_dir, distance, position)) {
                 distance = 0.0f; // "cheat", shapes/mod.rs:229-236
@@ -1107,7 +1108,7 @@ DEV LampSample lamp_sample(const DevLamp& lamp, Rng& rng, f3 target) {
         ls.normal = normalize(position - center);
         float d2 = dot(center - target, center - target);
         if (d2 > full_radius * full_radius) {
-            ls.weight = solid_angle(sqrtf(fmaxf(1.0f - (full_radius * full_radius) / d2, 0.0f)));
+            ls.weight = solid_angle(sqrt32(fmaxf(1.0f - (full_radius * full_radius) / d2, 0.0f)));
         } else {
             float cos_in = fabsf(dot(ls.normal, -ls.direction));
             ls.weight = cos_in * lamp.area / ls.sq_distance;
@@ -1319,7 +1320,7 @@ DEV void start_sample(const RenderLaunch& L, uint32_t tile, uint64_t iteration, 
         f3 target = mk(focus_x, -focus_y, -L.camera.focus_distance);
         f3 origin = mk(0, 0, 0), direction = target;
         if (L.camera.aperture > 0.0f) {
-            float sqrt_r = sqrtf(L.camera.aperture * rng_f32(p.rng));
+            float sqrt_r = sqrt32(L.camera.aperture * rng_f32(p.rng));
             float psi = PI_F * 2.0f * rng_f32(p.rng);
             origin = mk(sqrt_r * cos32(psi), sqrt_r * sin32(psi), 0.0f);
             direction = target - origin;
@@ -1743,7 +1744,8 @@ DEV void trav_ray_signs(Trav& t) {
     t.nz = (__float_as_uint(t.d.z) >> 31) * 48u;
 }
 // Puts a query whose ray, limit and plane results are set at the root of the tree.
-DEV float shadow_cutoff(float limit) { return sqrtf(limit * 1.001f + 1.0e-3f); } // +inf stays +inf; a negative limit gives NaN: nothing passes
+// v_sqrt_f32 alone: the ulp it may be off by is far inside the 0.1 % margin. +inf stays +inf; a negative limit gives NaN: nothing passes
+DEV float shadow_cutoff(float limit) { return __builtin_amdgcn_sqrtf(limit * 1.001f + 1.0e-3f); }
 // (t.inv is NOT set here: the kernels compute it where a ray is about to be stepped -- the stage scheduler at every entry of
 // its traversal phase -- so that the three registers are free while the other phases run.)
 DEV void trav_restart(Trav& t) {
