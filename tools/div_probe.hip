@@ -60,7 +60,14 @@ int main() {
                 if (ea >= 1 && ea <= 254 && eb >= 1 && eb <= 254) in += h[ea * 256 + eb];
         if (in == 0) { printf("clean for operand exponents within 2^+-%d of 1 (no condition on the quotient's)\n", K); break; }
     }
-    for (int d = 0; d < 512; ++d) if (by_diff[d]) printf("  exponent(a) - exponent(b) = %d: %llu\n", d - 256, by_diff[d]);
+    for (int eb = 1; eb < 255; ++eb) { // per denominator exponent: the numerator exponents with mismatches
+        int lo = 999, hi = -1, clean_lo = 999, clean_hi = -1;
+        for (int ea = 1; ea < 255; ++ea) {
+            if (h[ea * 256 + eb]) { lo = ea < lo ? ea : lo; hi = ea > hi ? ea : hi; }
+            else { clean_lo = ea < clean_lo ? ea : clean_lo; clean_hi = ea > clean_hi ? ea : clean_hi; }
+        }
+        printf("eb %d (2^%d): clean ea in [%d, %d] = quotient exponent 2^[%d, %d]%s\n", eb, eb - 127, clean_lo, clean_hi, clean_lo - eb, clean_hi - eb, hi >= 0 ? "" : " (all clean)");
+    }
     (void)lo_ea; (void)hi_ea; (void)lo_eb; (void)hi_eb; (void)min_diff; (void)max_diff;
     return 0;
 }
