@@ -339,11 +339,20 @@ DEV void texture_get(const DevScene& S, uint32_t id, float px, float py, float o
 
 // The register interpreter (program/execution_context.rs:69-283). Programs are pure functions of their input, so the
 // reference's memoised re-run (execute only wavelength-dependent instructions) and a full run give the same value.
-// `vector_out` (normal maps): receives the four components of a Vector program's output register.
-__device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgram& p, const VmInput& in, float* vector_out = nullptr) {
+// The register files and one instruction of the interpreter, as a body the stage scheduler's `contribute_now` runs in line:
+// the files persist between runs, so a program can be run in full for the hero wavelength and then, for every companion
+// wavelength, only the instructions that depend on the wavelength (PyrInstr::deps) -- the reference's memoised re-run
+// (program/memoized.rs:22-39, execution_context.rs:311-342): a texture is sampled once per hit, not once per wavelength.
+struct Vm {
     float num[PYR_MAX_NUMBER_REGISTERS];
     float vec[PYR_MAX_VECTOR_REGISTERS][4];
     float rgb[PYR_MAX_RGB_REGISTERS][4];
+    DEV void step(const DevScene& S, const PyrInstr& ins, const VmInput& in);
+    DEV float number(const DevProgram& p) const { return p.output_kind == PYR_OUTPUT_NUMBER ? num[p.output_reg & (PYR_MAX_NUMBER_REGISTERS - 1)] : vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][0]; }
+};
+
+// Vm::step: one instruction of the register interpreter (program/execution_context.rs:69-283).
+DEV void Vm::step(const DevScene& S, const PyrInstr& ins, const VmInput& in) {
     auto value = [&](const PyrOperand& o) -> float {
         if (o.kind == PYR_OPERAND_CONSTANT) return __uint_as_float(o.bits);
         if (o.kind == PYR_OPERAND_INPUT) return in.wavelength;
@@ -364,127 +373,130 @@ __device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgra
         default: return l / r;
         }
     };
-    for (uint32_t k = 0; k < p.num_instrs; ++k) {
-        const PyrInstr& ins = S.instrs[p.first_instr + k];
-        const uint32_t out = ins.output;
-        switch (ins.op) {
-        case PYR_OP_NUMBER: num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = __uint_as_float(ins.x.bits); break;
-        case PYR_OP_VECTOR: {
-            float x = value(ins.x), y = value(ins.y), z = value(ins.z), w = value(ins.w);
-            float* v = vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
-            v[0] = x, v[1] = y, v[2] = z, v[3] = w;
-            break;
-        }
-        case PYR_OP_RGB: {
-            float r = value(ins.x), g = value(ins.y), b = value(ins.z);
-            float* v = rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
-            v[0] = r, v[1] = g, v[2] = b, v[3] = 1.0f;
-            break;
-        }
-        case PYR_OP_SPECTRUM: num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = spectrum_get(S, ins.a, value(ins.x)); break;
-        case PYR_OP_COLOR_TEXTURE: { // execution_context.rs:114-126
-            float pos[4];
-            vinput(ins.b, pos);
-            float c[4];
-            texture_get(S, ins.a, pos[0], pos[1], c);
-            float* v = rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
-            for (int j = 0; j < 4; ++j) v[j] = c[j];
-            break;
-        }
-        case PYR_OP_MONO_TEXTURE: { // :127-139
-            float pos[4];
-            vinput(ins.b, pos);
-            float c[4];
-            texture_get(S, ins.a, pos[0], pos[1], c);
-            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = c[0];
-            break;
-        }
-        case PYR_OP_RGB_SPECTRUM: {
-            float wl = value(ins.x);
-            const float* c = rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
-            float resp[3] = {0, 0, 0};
-            uint32_t count = S.rgb_count;
-            if (count > 0) {
-                const float* d = S.rgb_basis;
-                if (wl <= S.rgb_min) {
-                    for (int j = 0; j < 3; ++j) resp[j] = d[j];
-                } else if (wl >= S.rgb_max) {
-                    for (int j = 0; j < 3; ++j) resp[j] = d[3 * (count - 1) + j];
-                } else {
-                    float normalized = (wl - S.rgb_min) / (S.rgb_max - S.rgb_min);
-                    float fi = normalized * ((float)count - 1.0f);
-                    float fmin_ = truncf(fi);
-                    uint32_t i0 = (uint32_t)fmin_;
-                    float mix = fi - fmin_;
-                    for (int j = 0; j < 3; ++j) resp[j] = d[3 * i0 + j] * (1.0f - mix) + d[3 * (i0 + 1) + j] * mix;
-                }
-            }
-            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = c[0] * resp[0] + c[1] * resp[1] + c[2] * resp[2];
-            break;
-        }
-        case PYR_OP_FRESNEL: {
-            float ior = value(ins.x), env = value(ins.y);
-            float nn[4], ii[4];
-            vinput(ins.a, nn);
-            vinput(ins.b, ii);
-            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = fresnel(ior, env, mk(nn[0], nn[1], nn[2]), mk(ii[0], ii[1], ii[2]));
-            break;
-        }
-        case PYR_OP_BLACKBODY: {
-            float wl = value(ins.x), temp = value(ins.y);
-            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = blackbody(wl, temp);
-            break;
-        }
-        case PYR_OP_RGB_TO_VECTOR: {
-            const float* c = rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
-            float* v = vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
-            for (int j = 0; j < 4; ++j) v[j] = (c[j] * 2.0f) - 1.0f;
-            break;
-        }
-        case PYR_OP_MIX: {
-            float amount = fmaxf(fminf(value(ins.x), 1.0f), 0.0f);
-            if (ins.value_type == PYR_VT_NUMBER) {
-                float l = num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], r = num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)];
-                num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = l * (1.0f - amount) + r * amount;
-            } else {
-                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
-                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)];
-                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
-                float t[4];
-                for (int j = 0; j < 4; ++j) t[j] = l[j] + (r[j] - l[j]) * amount;
-                for (int j = 0; j < 4; ++j) o[j] = t[j];
-            }
-            break;
-        }
-        case PYR_OP_BINARY: {
-            if (ins.value_type == PYR_VT_NUMBER) {
-                num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = binop(ins.operator_, num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)]);
-            } else {
-                float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
-                float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)];
-                float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
-                float t[4];
-                for (int j = 0; j < 4; ++j) t[j] = binop(ins.operator_, l[j], r[j]);
-                for (int j = 0; j < 4; ++j) o[j] = t[j];
-            }
-            break;
-        }
-        case PYR_OP_CLAMP: {
-            float v = value(ins.x), mn = value(ins.y), mx = value(ins.z);
-            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = fmaxf(fminf(v, mx), mn);
-            break;
-        }
-        default: break;
-        }
+    const uint32_t out = ins.output;
+    switch (ins.op) {
+    case PYR_OP_NUMBER: num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = __uint_as_float(ins.x.bits); break;
+    case PYR_OP_VECTOR: {
+        float x = value(ins.x), y = value(ins.y), z = value(ins.z), w = value(ins.w);
+        float* v = vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
+        v[0] = x, v[1] = y, v[2] = z, v[3] = w;
+        break;
     }
+    case PYR_OP_RGB: {
+        float r = value(ins.x), g = value(ins.y), b = value(ins.z);
+        float* v = rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
+        v[0] = r, v[1] = g, v[2] = b, v[3] = 1.0f;
+        break;
+    }
+    case PYR_OP_SPECTRUM: num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = spectrum_get(S, ins.a, value(ins.x)); break;
+    case PYR_OP_COLOR_TEXTURE: { // execution_context.rs:114-126
+        float pos[4];
+        vinput(ins.b, pos);
+        float c[4];
+        texture_get(S, ins.a, pos[0], pos[1], c);
+        float* v = rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
+        for (int j = 0; j < 4; ++j) v[j] = c[j];
+        break;
+    }
+    case PYR_OP_MONO_TEXTURE: { // :127-139
+        float pos[4];
+        vinput(ins.b, pos);
+        float c[4];
+        texture_get(S, ins.a, pos[0], pos[1], c);
+        num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = c[0];
+        break;
+    }
+    case PYR_OP_RGB_SPECTRUM: {
+        float wl = value(ins.x);
+        const float* c = rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+        float resp[3] = {0, 0, 0};
+        uint32_t count = S.rgb_count;
+        if (count > 0) {
+            const float* d = S.rgb_basis;
+            if (wl <= S.rgb_min) {
+                for (int j = 0; j < 3; ++j) resp[j] = d[j];
+            } else if (wl >= S.rgb_max) {
+                for (int j = 0; j < 3; ++j) resp[j] = d[3 * (count - 1) + j];
+            } else {
+                float normalized = (wl - S.rgb_min) / (S.rgb_max - S.rgb_min);
+                float fi = normalized * ((float)count - 1.0f);
+                float fmin_ = truncf(fi);
+                uint32_t i0 = (uint32_t)fmin_;
+                float mix = fi - fmin_;
+                for (int j = 0; j < 3; ++j) resp[j] = d[3 * i0 + j] * (1.0f - mix) + d[3 * (i0 + 1) + j] * mix;
+            }
+        }
+        num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = c[0] * resp[0] + c[1] * resp[1] + c[2] * resp[2];
+        break;
+    }
+    case PYR_OP_FRESNEL: {
+        float ior = value(ins.x), env = value(ins.y);
+        float nn[4], ii[4];
+        vinput(ins.a, nn);
+        vinput(ins.b, ii);
+        num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = fresnel(ior, env, mk(nn[0], nn[1], nn[2]), mk(ii[0], ii[1], ii[2]));
+        break;
+    }
+    case PYR_OP_BLACKBODY: {
+        float wl = value(ins.x), temp = value(ins.y);
+        num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = blackbody(wl, temp);
+        break;
+    }
+    case PYR_OP_RGB_TO_VECTOR: {
+        const float* c = rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+        float* v = vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
+        for (int j = 0; j < 4; ++j) v[j] = (c[j] * 2.0f) - 1.0f;
+        break;
+    }
+    case PYR_OP_MIX: {
+        float amount = fmaxf(fminf(value(ins.x), 1.0f), 0.0f);
+        if (ins.value_type == PYR_VT_NUMBER) {
+            float l = num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], r = num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)];
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = l * (1.0f - amount) + r * amount;
+        } else {
+            float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float t[4];
+            for (int j = 0; j < 4; ++j) t[j] = l[j] + (r[j] - l[j]) * amount;
+            for (int j = 0; j < 4; ++j) o[j] = t[j];
+        }
+        break;
+    }
+    case PYR_OP_BINARY: {
+        if (ins.value_type == PYR_VT_NUMBER) {
+            num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = binop(ins.operator_, num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)]);
+        } else {
+            float* l = ins.value_type == PYR_VT_VECTOR ? vec[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.a & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float* r = ins.value_type == PYR_VT_VECTOR ? vec[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[ins.b & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float* o = ins.value_type == PYR_VT_VECTOR ? vec[out & (PYR_MAX_VECTOR_REGISTERS - 1)] : rgb[out & (PYR_MAX_VECTOR_REGISTERS - 1)];
+            float t[4];
+            for (int j = 0; j < 4; ++j) t[j] = binop(ins.operator_, l[j], r[j]);
+            for (int j = 0; j < 4; ++j) o[j] = t[j];
+        }
+        break;
+    }
+    case PYR_OP_CLAMP: {
+        float v = value(ins.x), mn = value(ins.y), mx = value(ins.z);
+        num[out & (PYR_MAX_NUMBER_REGISTERS - 1)] = fmaxf(fminf(v, mx), mn);
+        break;
+    }
+    default: break;
+    }
+}
+
+// A whole program, out of line. `vector_out` (normal maps): receives the four components of a Vector program's output register.
+__device__ __noinline__ float run_interpreter(const DevScene& S, const DevProgram& p, const VmInput& in, float* vector_out = nullptr) {
+    Vm vm;
+    for (uint32_t k = 0; k < p.num_instrs; ++k) vm.step(S, S.instrs[p.first_instr + k], in);
     if (p.output_kind == PYR_OUTPUT_NUMBER) {
-        const float n = num[p.output_reg & (PYR_MAX_NUMBER_REGISTERS - 1)];
+        const float n = vm.num[p.output_reg & (PYR_MAX_NUMBER_REGISTERS - 1)];
         if (vector_out) vector_out[0] = vector_out[1] = vector_out[2] = vector_out[3] = n;
         return n;
     }
     if (vector_out)
-        for (int j = 0; j < 4; ++j) vector_out[j] = vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][j];
-    return vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][0];
+        for (int j = 0; j < 4; ++j) vector_out[j] = vm.vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][j];
+    return vm.vec[p.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][0];
 }
 
 // ExecutionContext::run (execution_context.rs:29-56) with the three shapes every Cornell-family program has short-cut.
@@ -1014,9 +1026,14 @@ DEV void surface_textured(const DevScene& S, const Hit& hit, f3 o, f3 d, f3& pos
     if (normal_map >= 0) {
         const DevProgram prog = S.programs[normal_map];
         float v[4] = {prog.constant, prog.constant, prog.constant, prog.constant};
-        if (prog.kind != PYR_PROGRAM_CONSTANT) {
+        if (prog.kind != PYR_PROGRAM_CONSTANT) { // in line: an out-of-line call here spills the walker around itself
             const VmInput in{0.0f, normal, d, tx, ty};
-            run_interpreter(S, prog, in, v);
+            Vm vm;
+            for (uint32_t k = 0; k < prog.num_instrs; ++k) vm.step(S, S.instrs[prog.first_instr + k], in);
+            if (prog.output_kind == PYR_OUTPUT_NUMBER)
+                v[0] = v[1] = v[2] = v[3] = vm.num[prog.output_reg & (PYR_MAX_NUMBER_REGISTERS - 1)];
+            else
+                for (int j = 0; j < 4; ++j) v[j] = vm.vec[prog.output_reg & (PYR_MAX_VECTOR_REGISTERS - 1)][j];
         }
         normal = normalize(quat_rotate(frame, mk(v[0], v[1], v[2])));
     }
@@ -1796,7 +1813,7 @@ typedef __attribute__((address_space(3))) int lds_int;
 struct TravStack {
     lds_int* lds; // + threadIdx.x; an LDS pointer by type: a generic one makes every push and pop a flat_ access that drains both counters
     int lds_entries;
-    int deep[kMaxStackDepth];
+    int* deep; // the lane's scratch part: kMaxStackDepth entries, or one where the whole stack is known to be in LDS (a scene staged in LDS)
     DEV void push(int sp, int value) {
         if (sp < lds_entries)
             lds[sp * BLOCK] = value;
@@ -2360,6 +2377,75 @@ struct Walker {
     // what this visit changed, for schedulers that keep the state in memory between phases (dead code elsewhere)
     uint32_t touched = 0;
 
+    // Interpreter builds (INTERP, no tape): what `contribute` (renderer/algorithm.rs:14-100) is to be applied to by the phase
+    // that has just run -- at most one program evaluation (a bounce's colour, an emission / sky / light-sample addition) and
+    // the bounce's closing BRDF factor -- is noted here and applied by contribute_pending() right behind the phases: ONE
+    // in-line copy of the interpreter instead of eleven out-of-line calls (each of which spilled the walker around itself:
+    // 558 VGPR spills, 2.1 KB of scratch per lane), and one memoised run per hit instead of one full run per wavelength.
+    // Order is the reference's: the program's contribution first, then the BRDF factor; nothing else touches brightness or
+    // reflectance in between (a lane enters SHADE and then NEE in one turn at most, and NEE's first visit adds nothing).
+    enum : uint32_t { CONTRIB_NONE = 0, CONTRIB_MUL = 1, CONTRIB_ADD = 2 };
+    uint32_t c_kind = CONTRIB_NONE, c_color = 0;
+    int c_probability = -1;  // a probability program to evaluate at the hero wavelength: cp = value * c_cp; else cp = c_cp
+    float c_cp = 1.0f, c_outer = 1.0f, c_scale = 1.0f;
+    bool c_use_outer = false, c_companions = false, c_has_scale = false;
+    f3 c_normal = mk(0, 0, 0), c_incident = mk(0, 0, 0);
+    float c_tx = 0.0f, c_ty = 0.0f;
+    DEV void contribution(uint32_t kind, uint32_t color, int probability, float cp, bool use_outer, float outer, bool companions, f3 normal, f3 incident, float tx,
+                          float ty) {
+        c_kind = kind, c_color = color, c_probability = probability, c_cp = cp, c_use_outer = use_outer, c_outer = outer, c_companions = companions;
+        c_normal = normal, c_incident = incident, c_tx = tx, c_ty = ty;
+    }
+    DEV void contribute_pending(const DevScene& S, const RenderLaunch& L, Spectral& spec) {
+        if constexpr (INTERP && !TAPE) {
+            const uint32_t n_add = L.spectrum_samples - 1;
+            if (c_kind != CONTRIB_NONE) {
+                VmInput in{p.wl, c_normal, c_incident, c_tx, c_ty};
+                Vm vm;
+                float cp = c_cp, factor = 0.0f;
+                // job 0: the probability program (hero wavelength only: ProbabilityInput), job 1: the colour program for the hero
+                // and, memoised, for the companions
+                for (uint32_t job = c_probability >= 0 ? 0u : 1u; job < 2u; ++job) {
+                    const uint32_t id = job == 0u ? (uint32_t)c_probability : c_color;
+                    const DevProgram prog = S.programs[id];
+                    const bool interpreted = prog.kind != PYR_PROGRAM_CONSTANT && prog.fast == FAST_NONE;
+                    const Prepared q = prepare_program<false>(S, id);
+                    const uint32_t passes = (job == 1u && c_companions) ? 1u + n_add : 1u;
+                    if (job == 1u) factor = c_use_outer ? c_outer * cp : cp;
+                    for (uint32_t pass = 0; pass < passes; ++pass) {
+                        in.wavelength = pass == 0u ? p.wl : spec.wl(pass - 1u);
+                        float v;
+                        if (interpreted) {
+                            for (uint32_t k = 0; k < prog.num_instrs; ++k) {
+                                const PyrInstr& ins = S.instrs[prog.first_instr + k];
+                                if (pass == 0u || (ins.deps & PYR_DEP_WAVELENGTH) != 0u) vm.step(S, ins, in);
+                            }
+                            v = vm.number(prog);
+                        } else {
+                            v = eval_prepared<false>(S, q, in);
+                        }
+                        if (job == 0u) {
+                            cp = v * c_cp;
+                        } else if (pass == 0u) {
+                            if (c_kind == CONTRIB_MUL) p.refl *= v * factor;
+                            else p.bright += v * factor * p.refl;
+                        } else {
+                            if (c_kind == CONTRIB_MUL) spec.refl(pass - 1u) *= v * factor;
+                            else spec.bright(pass - 1u) += v * factor * spec.refl(pass - 1u);
+                        }
+                    }
+                }
+                c_kind = CONTRIB_NONE;
+            }
+            if (c_has_scale) {
+                p.refl *= c_scale;
+                if (p.use_additional)
+                    for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= c_scale;
+                c_has_scale = false;
+            }
+        }
+    }
+
     // tracer.rs:288-301 tail of a bounce + loop head :221: reflectance *= brdf, next ray, bounce count
     DEV void finish_bounce(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt) {
         const uint32_t n_add = L.spectrum_samples - 1;
@@ -2367,6 +2453,9 @@ struct Walker {
             const float brdf = 2.0f * fabsf(dot(b_out, b_normal));
             if constexpr (TAPE) {
                 tape_push(L, TAPE_SCALE, 0u, brdf);
+            } else if constexpr (INTERP) {
+                c_scale = brdf, c_has_scale = true; // behind this turn's contribution (contribute_pending)
+                if (p.use_additional) touched |= TOUCH_REFL;
             } else {
                 p.refl *= brdf;
                 if (p.use_additional) {
@@ -2436,6 +2525,8 @@ struct Walker {
             }
             if constexpr (TAPE) {
                 tape_push(L, TAPE_ADD, color, 1.0f);
+            } else if constexpr (INTERP) {
+                contribution(CONTRIB_ADD, color, -1, 1.0f, false, 1.0f, p.use_additional, -ray_d, ray_d, 0.0f, 0.0f);
             } else {
                 const Prepared q_prog = prepare_program<INTERP>(S, color);
                 VmInput in{p.wl, -ray_d, ray_d};
@@ -2463,9 +2554,14 @@ struct Walker {
         const PyrComponent comp = S.components[material.first_component + pick];
         float component_probability = comp.selection_compensation;
         bool normal_dispersed = false;
+        int deferred_probability = -1; // interpreter builds evaluate it with the colour program (contribute_pending)
         if (comp.probability_program >= 0) {
-            VmInput pin{p.wl, normal, ray_d, tx, ty};
-            component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+            if constexpr (INTERP && !TAPE) {
+                deferred_probability = comp.probability_program;
+            } else {
+                VmInput pin{p.wl, normal, ray_d, tx, ty};
+                component_probability = run_program<INTERP>(S, (uint32_t)comp.probability_program, pin) * comp.selection_compensation;
+            }
             normal_dispersed = S.programs[comp.probability_program].reads_wavelength != 0;
         }
         if (comp.bsdf == PYR_BSDF_EMISSIVE) {
@@ -2473,6 +2569,8 @@ struct Walker {
                 p.use_additional = !normal_dispersed && p.use_additional;
                 if constexpr (TAPE) {
                     tape_push(L, TAPE_ADD, comp.color_program, component_probability);
+                } else if constexpr (INTERP) {
+                    contribution(CONTRIB_ADD, comp.color_program, deferred_probability, comp.selection_compensation, false, 1.0f, p.use_additional, normal, ray_d, tx, ty);
                 } else {
                     const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
                     VmInput in{p.wl, normal, ray_d, tx, ty};
@@ -2512,6 +2610,10 @@ struct Walker {
         p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
         if constexpr (TAPE) {
             tape_push(L, TAPE_MUL, comp.color_program, bounce_probability);
+        } else if constexpr (INTERP) {
+            // bounce_probability = scatter_probability * (probability program's value * compensation), formed where the value is
+            contribution(CONTRIB_MUL, comp.color_program, deferred_probability, comp.selection_compensation, true, scatter_probability, p.use_additional, normal, ray_d, tx,
+                         ty);
         } else {
             const Prepared q_prog = prepare_program<INTERP>(S, comp.color_program);
             VmInput in{p.wl, normal, ray_d, tx, ty};
@@ -2560,14 +2662,19 @@ struct Walker {
                 float material_probability = 1.0f;
                 bool l_dispersed = false;
                 f3 target_normal = -t.d;
+                int deferred_probability = -1; // interpreter builds evaluate it with the colour program (contribute_pending)
                 if (ls_physical) {
                     const PyrMaterial lm = S.materials[ls_material];
                     const uint32_t e_pick = rng_choose(p.rng, lm.num_emissive);
                     const PyrComponent ec = S.components[lm.first_emissive + e_pick];
                     material_probability = ec.selection_compensation;
                     if (ec.probability_program >= 0) {
-                        VmInput pin{p.wl, ls_normal, t.d, ls_tx, ls_ty};
-                        material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                        if constexpr (INTERP && !TAPE) {
+                            deferred_probability = ec.probability_program;
+                        } else {
+                            VmInput pin{p.wl, ls_normal, t.d, ls_tx, ls_ty};
+                            material_probability = run_program<INTERP>(S, (uint32_t)ec.probability_program, pin) * ec.selection_compensation;
+                        }
                         l_dispersed = S.programs[ec.probability_program].reads_wavelength != 0;
                     }
                     l_color = ec.color_program;
@@ -2577,6 +2684,10 @@ struct Walker {
                 touched |= TOUCH_BRIGHT;
                 if constexpr (TAPE) {
                     tape_push(L, TAPE_ADD, l_color, l_probability, l_dispersed);
+                } else if constexpr (INTERP) {
+                    // l_probability = ls_scale * (probability program's value * compensation); the material's inputs are the light's
+                    contribution(CONTRIB_ADD, l_color, deferred_probability, material_probability, true, ls_scale, p.use_additional && !l_dispersed, target_normal, t.d,
+                                 ls_physical ? ls_tx : 0.0f, ls_physical ? ls_ty : 0.0f);
                 } else {
                     const Prepared q_prog = prepare_program<INTERP>(S, l_color);
                     VmInput in{p.wl, target_normal, t.d, ls_physical ? ls_tx : 0.0f, ls_physical ? ls_ty : 0.0f};
@@ -2857,8 +2968,15 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
     return n_spectral > kTapeOneSlot ? 0u : n_spectral; // too many for the reserved rows (the last one holds 1.0): the replay looks them up record by record
 }
 
+// Interpreter builds keep the program interpreter in line (Walker::contribute_pending): register files, a bicubic texture
+// look-up's sixteen texels and the walker do not fit 128 VGPRs -- at four waves per SIMD the kernel spilled 340 of them
+// and spent 87 % of its wave cycles waiting for scratch (profiles/r03_textures_interpreter_baseline.txt) -- so they are built for
+// PYR_SM_WAVES_INTERP waves per SIMD.
+#ifndef PYR_SM_WAVES_INTERP
+#define PYR_SM_WAVES_INTERP 2
+#endif
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
-__global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
+__global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     constexpr bool TAPE = !INTERP; // see "Spectral tape"
     const uint32_t SS = L.spectrum_samples;
@@ -2866,6 +2984,8 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
     // LDS rows of 256 floats: TAPE: S wavelengths + one row of per-wave lane lists; else wavelengths / brightness / reflectance
     const uint32_t spectral_rows = TAPE ? SS + 1 + kTapeEagerSlots : 3 * SS;
     TravStack stack;
+    int deep_levels[LDS_SCENE ? 1 : kMaxStackDepth]; // a scene that lives in LDS has its whole stack there (launch_render)
+    stack.deep = deep_levels;
     stack.lds = (lds_int*)(reinterpret_cast<int*>(lds + spectral_rows * BLOCK) + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
@@ -2941,6 +3061,12 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_sm(DevScene
             nN = __popcll(ballot64(w.stage == ST_NEE));
             nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
         }
+        if constexpr (INTERP) { // what SHADE / NEE of this turn noted for `contribute`: one in-line interpreter (Walker::contribute_pending)
+            if (ballot64(w.c_kind != 0u || w.c_has_scale) != 0ull) {
+                const RenderLaunch& Lp = launch_from_kernarg(L);
+                w.contribute_pending(scene_view(Lp), Lp, spec);
+            }
+        }
         // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
         if (nT >= phase_lanes || nT == max(max(nT, nS), max(nN, nE))) {
 #ifdef PYR_PHASE_PROFILE
@@ -3011,6 +3137,8 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_split(DevSc
     const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots;
     int* stack_rows = reinterpret_cast<int*>(lds + spectral_rows * BLOCK);
     TravStack stack;
+    int deep_levels[kMaxStackDepth];
+    stack.deep = deep_levels;
     stack.lds = (lds_int*)(stack_rows + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
@@ -3252,6 +3380,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(DevScene S, IntersectLaunch L) {
     extern __shared__ int lds_stack[];
     TravStack stack;
+    int deep_levels[kMaxStackDepth];
+    stack.deep = deep_levels;
     stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)L.stack_lds;
     Counters cnt{};
@@ -3479,6 +3609,7 @@ __global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderL
         if (!(any_shade || any_nee || any_end)) break; // every lane holds a ray to trace, or is done
         if (any_shade) w.shade(S, L, spec, cnt);
         if (ballot64(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
+        if constexpr (INTERP) w.contribute_pending(S, L, spec); // before a path that has just ended is exposed
         if (ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
     }
     if (had_work) wf_store(P, slot, planes, w, spec, n_comp);
@@ -3648,6 +3779,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void wf_trav_kernel(DevScene S, WfPool P, uint32_t reserve, uint32_t stack_lds, unsigned long long* counters) {
     extern __shared__ int lds_stack[];
     TravStack stack;
+    int deep_levels[kMaxStackDepth];
+    stack.deep = deep_levels;
     stack.lds = (lds_int*)(lds_stack + threadIdx.x);
     stack.lds_entries = (int)stack_lds;
     Counters cnt{};
@@ -3912,6 +4045,9 @@ static RenderKernel pick_tables(bool sm, bool lds_tables) {
 #ifdef PYR_DEV_ONLY_SM // developer builds for reading the ISA (tools/asm_sm.sh): only the kernel the BASELINE meshes run is instantiated
     return render_kernel_sm<false, false, false, true>;
 #endif
+#ifdef PYR_DEV_ONLY_SM_INTERP // ... or only the interpreter build the reference's textures example runs
+    return render_kernel_sm<false, true, true, false>;
+#endif
     if (sm) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
     return lds_tables ? render_kernel<C, I, L, true> : render_kernel<C, I, L, false>;
 }
@@ -3935,7 +4071,12 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.stack_lds = 0;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernels are built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
-    launch.stack_lds = launch.scheduler == 1 || launch.scheduler == 3 ? short_stack_levels(scene, render_lds_bytes(scene, launch), PYR_SM_WAVES) : scene.stack_depth;
+    launch.stack_lds = launch.scheduler == 1 || launch.scheduler == 3
+                           ? short_stack_levels(scene, render_lds_bytes(scene, launch), launch.scheduler == 1 && scene.needs_interpreter != 0 ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
+                           : scene.stack_depth;
+    // a scene staged in LDS is a few dozen nodes: its whole stack is kept in LDS (the kernels built for such scenes have no
+    // scratch part), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below still applies
+    if (launch.scheduler == 1 && scene_fits_lds(scene)) launch.stack_lds = std::max(launch.stack_lds, scene.stack_depth);
     // the split scheduler walks four-child trees with triangle pairs only, keeps its slots in the stack rows and has no
     // interpreter form: anything else runs on the stage scheduler
     if (launch.scheduler == 3 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene) || launch.stack_lds < kSplitRows)) {
