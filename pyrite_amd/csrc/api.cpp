@@ -683,8 +683,9 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 2;
     else if (e && std::string(e) == "split")
         L.scheduler = 3;
-    else
-        L.scheduler = scene_is_lds_resident(scene->dev) ? 0u : 1u;
+    else // the synchronous walk for scenes that live in LDS -- unless they run interpreter programs: the stage scheduler keeps the
+         // interpreter in line and memoised (spheres example 572 -> 737, lamps 549 -> 724 Msamples/s against the synchronous walk)
+        L.scheduler = scene_is_lds_resident(scene->dev) && scene->dev.needs_interpreter == 0 ? 0u : 1u;
     // texture coordinates and normal maps live in the resumable integrator (Walker); the synchronous walk has no texture path
     if (L.scheduler == 0 && scene->dev.uses_textures) L.scheduler = 1;
     if (L.scheduler == 2) {

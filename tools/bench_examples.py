@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Developer tool: the reference's example scenes (interpreter programs) at their projects' own sizes, per scheduler.
+    python tools/bench_examples.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from pyrite_amd import abi, scenes  # noqa: E402
+
+dev = torch.device("cuda", 0)
+cases = {
+    "spheres 512x256x600": scenes.spheres_example(512, 256, 600),
+    "diamonds 512x300x200 (256 bounces)": scenes.diamonds_example(512, 300, 200, bounces=256),
+    "lamps 384x256x256": scenes.lamps_example(384, 256, 256),
+    "textures 1024x512x400": scenes.textures_reference_example(os.path.join(ROOT, "tests", "golden", "textures"), 1024, 512, 400),
+}
+for name, project in cases.items():
+    world, cam, r, _ = scenes.build(project, seed=1)
+    world.scene(0)
+    W, H = project["image"]["width"], project["image"]["height"]
+    film = torch.zeros((H, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+    desc = abi.PyrFilmDesc(W, H, r.spectrum_bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
+    stream = torch.cuda.current_stream(dev)
+    for sched in ("", "sync", "sm"):
+        if sched:
+            os.environ["PYRITE_SCHEDULER"] = sched
+        else:
+            os.environ.pop("PYRITE_SCHEDULER", None)
+        best = None
+        try:
+            for _ in range(3):
+                film.zero_()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                r.render_device(film.data_ptr(), desc, cam, world, stream=stream.cuda_stream, device=0)
+                b.record(stream)
+                torch.cuda.synchronize(dev)
+                ms = a.elapsed_time(b)
+                best = ms if best is None else min(best, ms)
+            print("%-36s %-8s %9.2f ms %8.1f Msamples/s" % (name, sched or "default", best, W * H * r.pixel_samples / best / 1e3), flush=True)
+        except Exception as e:  # noqa: BLE001
+            print("%-36s %-8s failed: %s" % (name, sched or "default", e), flush=True)
+    world.close()
