@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def have(*parts):
@@ -71,11 +71,15 @@ if os.path.exists(os.path.join(DST, "traffic.json")):
     with open(os.path.join(DST, "traffic.json")) as f:
         traffic = json.load(f)
 
-for cfg, timed_kernel, label in (("c3", "render_kernel_sm<false", "C3"), ("c2", "render_kernel<false", "C2")):
-    if not have(cfg + "_trace", cfg + "_kernel_stats.csv"):
+for cfg, timed_kernel, label in (("c3", "render_kernel_sm<false", "C3"), ("c2", "render_kernel<false", "C2"), ("c5", "render_kernel_sm<false", "C5")):
+    trace = cfg + "_trace_full" if cfg == "c5" else cfg + "_trace"  # C5's plain trace is a reduced-spp run; the traffic belongs to the full launch
+    if not have(trace, cfg + "_kernel_stats.csv"):
         continue
-    copy("%s_trace/%s_kernel_stats.csv" % (cfg, cfg), "%s_kernel_stats.csv" % cfg)
-    ms, calls = kernel_average_ms(os.path.join(SRC, cfg + "_trace", cfg + "_kernel_stats.csv"), timed_kernel)
+    if cfg != "c5":
+        copy("%s/%s_kernel_stats.csv" % (trace, cfg), "%s_kernel_stats.csv" % cfg)
+    else:
+        copy("%s/%s_kernel_stats.csv" % (trace, cfg), "c5_full_kernel_stats.csv")
+    ms, calls = kernel_average_ms(os.path.join(SRC, trace, cfg + "_kernel_stats.csv"), timed_kernel)
     if have(cfg + "_fetch", "fetch_counter_collection.csv") and have(cfg + "_write", "write_counter_collection.csv"):
         keep_our_rows(cfg + "_fetch/fetch_counter_collection.csv", "%s_%s_pmc_fetch_size.csv" % (tag, cfg))
         keep_our_rows(cfg + "_write/write_counter_collection.csv", "%s_%s_pmc_write_size.csv" % (tag, cfg))
