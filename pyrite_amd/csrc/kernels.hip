@@ -183,6 +183,9 @@ DEV float rng_range_f32(Rng& r, float low, float high) {
     }
 }
 // UniformInt<usize>::sample_single: 64-bit draw, widening multiply by `n` (< 2^32), rejection zone.
+// (rand's zone rejects up to half the draws and a wave stays in these loops until its unluckiest lane is through: ~5 turns per
+// call, a third of a SHADE visit. Written four draws per turn with the state's rotation spelled out -- no register moves per
+// draw -- the loops were 2.5 % SLOWER on C3 (520 against 531-535 Msamples/s): four exits per turn cost more than the moves.)
 DEV uint32_t rng_range_usize(Rng& r, uint32_t n) {
     uint64_t range = n;
     uint64_t zone = (range << __builtin_clzll(range)) - 1;
@@ -3008,8 +3011,11 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
     // programs that read a spectrum get a slot (their rank among such programs); the slot -> program list follows the table
     uint32_t n_spectral = 0;
     float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
-    spectral_values[kTapeOneSlot * BLOCK] = 1.0f; // eager records of constant programs and BRDF factors (tape_push)
     if constexpr (TAPE) {
+        // eager records of constant programs and BRDF factors (tape_push). TAPE builds only: without the tape these rows are not
+        // reserved, and with few wavelengths the store landed in the staged scene (found by the fuzz campaign of round 3: two
+        // wavelengths, a tree four levels deep -- row SS + 8 was the first KB of the LDS copy of the nodes)
+        spectral_values[kTapeOneSlot * BLOCK] = 1.0f;
         n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
         if (n_spectral != 0) w.tape_prepared = prepared_lds;
         w.tape_column = blockIdx.x * BLOCK + threadIdx.x;

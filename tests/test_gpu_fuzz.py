@@ -115,8 +115,14 @@ def random_project(seed):
     }
 
 
+# Seeds that once found something, always run: 37 (round 3) -- two wavelengths per sample and a tree four levels deep put the
+# staged scene where a store meant for the tape's value rows landed in builds without a tape (render_kernel_sm).
+REGRESSION_SEEDS = [37]
+SCENE_SEEDS = sorted(set(range(int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "12")))) | set(REGRESSION_SEEDS))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", SCENE_SEEDS)
 def test_random_scene_matches_the_oracle_on_every_scheduler(seed, gpu_lib, monkeypatch):
     project = random_project(1000 + seed)
     world, cam, r, _ = scenes.build(project, seed=seed)
