@@ -686,8 +686,9 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     else // the synchronous walk for scenes that live in LDS -- unless they run interpreter programs: the stage scheduler keeps the
          // interpreter in line and memoised (spheres example 572 -> 737, lamps 549 -> 724 Msamples/s against the synchronous walk)
         L.scheduler = scene_is_lds_resident(scene->dev) && scene->dev.needs_interpreter == 0 ? 0u : 1u;
-    // texture coordinates and normal maps live in the resumable integrator (Walker); the synchronous walk has no texture path
-    if (L.scheduler == 0 && scene->dev.uses_textures) L.scheduler = 1;
+    // the program interpreter (and with it texture coordinates and normal maps) lives in the resumable integrator (Walker), in
+    // line; the synchronous walk is built without it: PYRITE_SCHEDULER=sync on such a scene runs the stage scheduler
+    if (L.scheduler == 0 && scene->dev.needs_interpreter != 0) L.scheduler = 1;
     if (L.scheduler == 2) {
         WfPool pool{};
         int rc = wavefront_pool(scene, L, pool);

@@ -3565,7 +3565,7 @@ __global__ __launch_bounds__(BLOCK) void wf_init_kernel(WfPool P, uint32_t chunk
 }
 
 template <bool COUNT, bool INTERP>
-__global__ __launch_bounds__(BLOCK, 4) void wf_logic_kernel(DevScene S0, RenderLaunch L, WfPool P) {
+__global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : 4) void wf_logic_kernel(DevScene S0, RenderLaunch L, WfPool P) {
     extern __shared__ float lds[];
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
@@ -4054,8 +4054,10 @@ static RenderKernel pick_tables(bool sm, bool lds_tables) {
 #ifdef PYR_DEV_ONLY_SM_INTERP // ... or only the interpreter build the reference's textures example runs
     return render_kernel_sm<false, true, true, false>;
 #endif
-    if (sm) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
-    return lds_tables ? render_kernel<C, I, L, true> : render_kernel<C, I, L, false>;
+    // the synchronous walk is built without the interpreter only: a scene with interpreter programs runs on the stage scheduler,
+    // which keeps the interpreter in line (api.cpp render_batches routes it there; this keeps the out-of-line builds out of the library)
+    if (sm || I) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
+    return lds_tables ? render_kernel<C, false, L, true> : render_kernel<C, false, L, false>;
 }
 template <bool C, bool I>
 static RenderKernel pick_scene(bool sm, bool lds_scene, bool lds_tables) {
