@@ -333,6 +333,8 @@ class Workload:
             "traffic": traffic,
             "traffic_source": traffic_source,
             "measured_hbm_GBps": round(traffic / ((traffic_ms or kernel_ms) * 1e-3) / 1e9, 1) if traffic else None,
+            "measured_hbm_frac": round(traffic / ((traffic_ms or kernel_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "frac_is": "algorithmic-bytes rate / HBM peak (the contract's roofline definition), NOT achieved memory bandwidth: that is measured_hbm_frac",
             "compared_with_target": "frac = algorithmic bytes / kernel time / 8 TB/s is what north_star's >= 0.40 is compared with",
             "kernel": self.kernel_name(),
             "kernel_ms": round(kernel_ms, 3),
