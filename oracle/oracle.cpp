@@ -1806,6 +1806,7 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
         additional_samples.pop_back();
         float wavelength = main_sample.wavelength;
 
+        const Ray camera_ray = ray;
         trace(s, path, lights, rng, ray, wavelength, p.bounces, p.light_samples, exe, c);
 
         bool use_additional = true;
@@ -1818,12 +1819,14 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
             unsigned dx = 0, dy = 0;
             uint64_t qx, qy;
             if (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy) {
-                std::fprintf(stderr, "[oracle] tile %u iteration %llu hero %.3f nm brightness %.9g use_additional %d bounces %zu\n", tile.raster_index,
+                std::fprintf(stderr, "[oracle] tile %u iteration %llu hero %.9g nm brightness %.9g use_additional %d bounces %zu\n", tile.raster_index,
                              (unsigned long long)i, main_sample.wavelength, main_sample.brightness, (int)use_additional, path.size());
+                std::fprintf(stderr, "    camera ray origin (%.9g %.9g %.9g) direction (%.9g %.9g %.9g)\n", camera_ray.origin.x, camera_ray.origin.y, camera_ray.origin.z,
+                             camera_ray.direction.x, camera_ray.direction.y, camera_ray.direction.z);
                 for (const Bounce& b : path) {
-                    std::fprintf(stderr, "    bounce type %d color %u prob %.9g dispersed %d pos (%.9g %.9g %.9g) normal (%.6f %.6f %.6f) out (%.6f %.6f %.6f) lights %zu:", (int)b.ty,
+                    std::fprintf(stderr, "    bounce type %d color %u prob %.9g dispersed %d pos (%.9g %.9g %.9g) normal (%.9g %.9g %.9g) out (%.9g %.9g %.9g) incident (%.9g %.9g %.9g) lights %zu:", (int)b.ty,
                                  b.color, b.probability, (int)b.dispersed, b.position.x, b.position.y, b.position.z, b.normal.x, b.normal.y, b.normal.z, b.out.x, b.out.y,
-                                 b.out.z, (size_t)b.light_count);
+                                 b.out.z, b.incident.x, b.incident.y, b.incident.z, (size_t)b.light_count);
                     for (uint32_t li = 0; li < b.light_count; ++li) {
                         const DirectLight& dl = lights[b.light_first + li];
                         std::fprintf(stderr, " [color %u prob %.9g dir (%.9g %.9g %.9g)]", dl.color, dl.probability, dl.incident.x, dl.incident.y, dl.incident.z);
