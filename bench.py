@@ -470,6 +470,23 @@ def main():
         if int(flag.item()) == 1:
             wl.use_native(comm)
             wl.collective = "pyr_render_simple_sharded (ncclSend/ncclRecv group inside libpyrite_gpu.so)"
+            # one untimed step through it before anything is timed: a gather that fails on this node (the library reports it on
+            # every rank, multi.cpp) sends all ranks to the other collective together instead of ending the run
+            try:
+                wl.step()
+                torch.cuda.synchronize(device)
+                comm.status()
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, str(e)
+            flag.fill_(ok)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            wl.launch_events.clear()
+            if int(flag.item()) != 1:
+                comm.close()
+                wl.native = None
+                if hasattr(wl, "native_film"):
+                    del wl.native_film
+                wl.collective = "torch.distributed.gather (RCCL); the native gather failed on some rank%s" % (": " + why if why else "")
         else:
             if comm is not None:
                 comm.close()

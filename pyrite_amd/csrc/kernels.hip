@@ -1936,13 +1936,8 @@ DEV WidePlanes load_wide_planes(const float4* wide_nodes, const Trav& t) {
 }
 template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
 DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-#if PYR_EXPERIMENT_UNSIGNED_GENERIC
-    const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
-    return wide_node_visit<COUNT, POSTPONE>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, stack, cnt);
-#else
     const WidePlanes n = load_wide_planes(view.nodes, t);
     return wide_node_visit<COUNT, POSTPONE, true>(n.nx, n.ny, n.nz, n.fx, n.fy, n.fz, n.ch, t, stack, cnt);
-#endif
 }
 
 // One primitive of a leaf, its record already loaded (a, b, c = the three vectors of a DevPrim): the tests and the
@@ -2214,9 +2209,6 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
 #ifndef PYR_LEAN_STEP
 #define PYR_LEAN_STEP 1
 #endif
-#ifndef PYR_SIGNED_PLANES
-#define PYR_SIGNED_PLANES 1 // the straight-line step picks a node's near / far planes by the ray's signs (trav_ray_signs)
-#endif
 template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
     if constexpr (POSTPONE && GLOBAL) {
@@ -2261,13 +2253,8 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
             const int top = stack.lds[below * BLOCK];
             float e[4];
             int c[4];
-#if PYR_SIGNED_PLANES
-            const WidePlanes pl = load_wide_planes(view.nodes, t);
+            const WidePlanes pl = load_wide_planes(view.nodes, t); // near / far planes picked by the ray's signs (trav_ray_signs)
             wide_node_children<COUNT, true>(pl.nx, pl.ny, pl.nz, pl.fx, pl.fy, pl.fz, pl.ch, t, cnt, e, c);
-#else
-            const ScenePtr<true> nd{view.nodes + 8 * (size_t)t.node};
-            wide_node_children<COUNT>(nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], nd[6], t, cnt, e, c);
-#endif
             const bool none = c[0] == INT32_MIN, hit1 = c[1] != INT32_MIN, hit2 = c[2] != INT32_MIN, hit3 = c[3] != INT32_MIN;
             const int n = (hit1 ? 1 : 0) + (hit2 ? 1 : 0) + (hit3 ? 1 : 0); // children to push: c[1 .. n], far to near
             const int above = t.sp + n;

@@ -1,30 +1,57 @@
 #!/usr/bin/env python3
-"""Developer tool: python tools/fuzz_trace.py SEED X Y -- the oracle's paths through pixel (X, Y) of a fuzz scene
-(ORACLE_DEBUG_PIXEL), and for every ray of them the closest hit of the oracle and of the GPU walk side by side: does a film
-difference start at a hit (a tie, a missed primitive) or in the shading arithmetic?"""
+"""Developer tool (GPU box): python tools/fuzz_trace.py scene|soup SEED [X Y] -- where does the GPU film of a fuzz case differ from
+the oracle's, and why? Finds the differing pixels (or takes one), prints the oracle's paths through the first of them
+(ORACLE_DEBUG_PIXEL) and walks the camera ray, every extension ray and every unblocked shadow ray of those paths through World::intersect on both sides:
+a film difference that starts at two primitives met at the same f32 distance is a tie, anything else is a defect."""
 import os, re, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-seed, x, y = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-if os.environ.get("ORACLE_DEBUG_PIXEL") is None:  # the oracle reads the variable once: run again with it set, stderr kept
-    env = dict(os.environ, ORACLE_DEBUG_PIXEL="%d,%d" % (x, y))
-    out = subprocess.run([sys.executable, __file__] + sys.argv[1:], env=env, stderr=subprocess.PIPE, text=True)
-    log = out.stderr
-    sys.stdout.flush()
-    open("/tmp/fuzz_trace_oracle.log", "w").write(log)
-    sys.exit(out.returncode)
+kind, seed = sys.argv[1], int(sys.argv[2])
+pixel = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else None
 
 import oracle
 from pyrite_amd import scenes
-from pyrite_amd.renderer import World
-from test_gpu_fuzz import random_project
+from pyrite_amd.project import camera, transform, vector
+from pyrite_amd.renderer import Camera, Renderer, World
+from test_gpu_fuzz import random_project, random_soup
+from test_gpu_parity import rel_l2
 
-project = random_project(1000 + seed)
-world, cam, r, _ = scenes.build(project, seed=seed)
-W, H = project["image"]["width"], project["image"]["height"]
-# pass 1: the oracle's render with its stderr into a file we read back
+
+def build():
+    if kind == "scene":
+        project = random_project(1000 + seed)
+        world, cam, r, _ = scenes.build(project, seed=seed)
+        return world, cam, r, project["image"]["width"], project["image"]["height"]
+    world = World(random_soup(2000 + seed))
+    r = Renderer(pixel_samples=3, bounces=6, light_samples=2, spectrum_samples=5, tile_size=16, seed=seed)
+    cam = Camera.from_project(camera.perspective(fov=60, transform=transform.look_at(**{"from": vector(0, -9, 1), "to": vector(0, 0, 0), "up": vector(z=1)})))
+    return world, cam, r, 40, 30
+
+
+world, cam, r, W, H = build()
+if pixel is None:  # pass 1: which pixels differ; then this script again for the first of them, with the oracle's printing switched on
+    cfilm = r.new_film(W, H)
+    oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    gfilm = r.new_film(W, H)
+    r.render(gfilm, cam, World(world.flat))
+    e = rel_l2(gfilm, cfilm).reshape(H, W)
+    wdiff = (gfilm.grains[..., 1] != cfilm.grains[..., 1]).any(axis=-1)
+    bad = np.argwhere((e > 1e-5) | wdiff)
+    print("%s %d: %d x %d, %d differing pixels:" % (kind, seed, W, H, len(bad)), [(int(x), int(y), float(e[y, x]), bool(wdiff[y, x])) for y, x in bad][:8])
+    sys.stdout.flush()
+    if len(bad):
+        y, x = bad[0]
+        g, c = gfilm.grains[y, x], cfilm.grains[y, x]
+        for b in np.nonzero((g[:, 0] != c[:, 0]) | (g[:, 1] != c[:, 1]))[0][:12]:
+            print("   bin %d: gpu %.9g (weight %g)  oracle %.9g (weight %g)  ratio %.9g" % (b, g[b, 0], g[b, 1], c[b, 0], c[b, 1], g[b, 0] / c[b, 0] if c[b, 0] else float("nan")))
+        sys.stdout.flush()
+        env = dict(os.environ, ORACLE_DEBUG_PIXEL="%d,%d" % (x, y))
+        sys.exit(subprocess.run([sys.executable, __file__, kind, str(seed), str(x), str(y)], env=env).returncode)
+    sys.exit(0)
+
+# pass 2: the oracle's render with its stderr (the paths through the pixel) in a file
 saved = os.dup(2)
 with open("/tmp/fuzz_trace_paths.log", "w") as f:
     os.dup2(f.fileno(), 2)
@@ -32,28 +59,38 @@ with open("/tmp/fuzz_trace_paths.log", "w") as f:
     oracle.OracleScene(world).render(r, cam, cfilm, threads=1)
     os.dup2(saved, 2)
 text = open("/tmp/fuzz_trace_paths.log").read()
-print(text)
 num = r"([-+0-9.einfa]+)"
 rays, tags = [], []
 for block in text.split("[oracle] tile")[1:]:
-    head = block.split("\n")[0]
+    head = block.split("\n")[0].strip()[:34]
     prev = None
     cam_line = re.search(r"camera ray origin \(%s %s %s\) direction \(%s %s %s\)" % ((num,) * 6), block)
     if cam_line:
         rays.append([float(v) for v in cam_line.groups()])
-        tags.append((head.strip()[:40], "camera"))
+        tags.append((head, "camera"))
     for k, line in enumerate(l for l in block.split("\n")[1:] if l.strip().startswith("bounce")):
         pos = [float(v) for v in re.search(r"pos \(%s %s %s\)" % (num, num, num), line).groups()]
         inc = [float(v) for v in re.search(r"incident \(%s %s %s\)" % (num, num, num), line).groups()]
-        if prev is not None:
+        if prev is not None and np.isfinite(prev).all():
             rays.append(prev + inc)
-            tags.append((head.strip()[:40], k))
+            tags.append((head, "bounce %d" % k))
         prev = pos
+        for j, m in enumerate(re.finditer(r"\[color \d+ prob %s dir \(%s %s %s\)\]" % (num, num, num, num), line)):
+            if np.isfinite(pos).all():  # the shadow rays the oracle found unblocked (blocked ones are not kept by trace_direct)
+                rays.append(pos + [float(v) for v in m.groups()[1:]])
+                tags.append((head, "bounce %d light %d (unblocked in the oracle)" % (k, j)))
+print("pixel", pixel, ":", len(text.split("[oracle] tile")) - 1, "samples,", len(rays), "rays")
+verdict = "no ray of the oracle's paths is answered differently: the difference is in the shading arithmetic (or in a shadow ray)"
 if rays:
     rays = np.array(rays, dtype=np.float32)
     oh, _ = oracle.OracleScene(world).intersect(rays)
-    gworld = World(world.flat)
-    gh, _, _ = gworld.intersect(rays)
+    gh, _, _ = World(world.flat).intersect(rays)
     for t, ray, a, b in zip(tags, rays, oh, gh):
-        same = a.tobytes() == b.tobytes()
-        print(t, "ray", ray, "\n   oracle", a, "\n   gpu   ", b, "" if same else "   <-- DIFFERENT")
+        if a.tobytes() != b.tobytes():
+            tie = float(a[0]) == float(b[0])
+            print(t, "ray", ray, "\n   oracle", a, "\n   gpu   ", b, "   <-- " + ("TIE: same f32 distance, another primitive" if tie else "DIFFERENT"))
+            verdict = "tie" if tie else "DEFECT: the closest hit differs"
+            break
+print("verdict:", verdict)
+if verdict.startswith("no ray"):
+    print(text)
