@@ -8,7 +8,10 @@
 namespace pyr {
 namespace {
 
-constexpr int kBins = 16;
+#ifndef PYR_SAH_BINS
+#define PYR_SAH_BINS 16
+#endif
+constexpr int kBins = PYR_SAH_BINS;
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
 struct Box {
