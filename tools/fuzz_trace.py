@@ -2,7 +2,9 @@
 """Developer tool (GPU box): python tools/fuzz_trace.py scene|soup SEED [X Y] -- where does the GPU film of a fuzz case differ from
 the oracle's, and why? Finds the differing pixels (or takes one), prints the oracle's paths through the first of them
 (ORACLE_DEBUG_PIXEL) and walks the camera ray, every extension ray and every unblocked shadow ray of those paths through World::intersect on both sides:
-a film difference that starts at two primitives met at the same f32 distance is a tie, anything else is a defect."""
+a film difference that starts at two primitives met at the same f32 distance is a tie, anything else is a defect.
+tools/fuzz_sched.py says which scheduler differs; for the synchronous walk of a big scene (two-child tree) give the pixel and
+set PYRITE_WIDE_BVH=0 ORACLE_DEBUG_PIXEL=X,Y so that World::intersect walks that tree too."""
 import os, re, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
