@@ -1406,6 +1406,26 @@ __device__ unsigned long long g_phase_prof[16];
 #define SLAP(sp, i)
 #endif
 
+// Wave priority per section of the synchronous walk (s_setprio; see PYR_PRIO_* of the stage scheduler for why): traversal on
+// top, the next-event estimation's own arithmetic below it, shading below that, exposure and sample start at the bottom.
+// C2 803 -> 827 Msamples/s. All four equal = no instruction emitted.
+#ifndef PYR_SYNC_PRIO_T
+#define PYR_SYNC_PRIO_T 3
+#endif
+#ifndef PYR_SYNC_PRIO_N
+#define PYR_SYNC_PRIO_N 2
+#endif
+#ifndef PYR_SYNC_PRIO_S
+#define PYR_SYNC_PRIO_S 1
+#endif
+#ifndef PYR_SYNC_PRIO_E
+#define PYR_SYNC_PRIO_E 0
+#endif
+#if PYR_SYNC_PRIO_T != PYR_SYNC_PRIO_N || PYR_SYNC_PRIO_N != PYR_SYNC_PRIO_S || PYR_SYNC_PRIO_S != PYR_SYNC_PRIO_E
+#define SYNC_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define SYNC_PRIO(x)
+#endif
 // One iteration of tracer::trace's loop (tracer.rs:221-344) with `contribute` (renderer/algorithm.rs:14-100) applied online.
 // Returns true when the path has ended (emission, miss). Does not touch p.bounce.
 template <bool COUNT, bool INTERP>
@@ -1414,7 +1434,9 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
     Hit hit;
     if (COUNT) cnt.extension_rays++;
     const f3 ray_o = p.o, ray_d = p.d;
+    SYNC_PRIO(PYR_SYNC_PRIO_T);
     const bool found = traverse<COUNT, false>(S, view.nodes, view.prims, ray_o, ray_d, 0.0f, hit, stack, cnt);
+    SYNC_PRIO(PYR_SYNC_PRIO_S);
     SLAP(sp, 1);
     if (!found) {
         // miss: first matching directional lamp (trace_directional, tracer.rs:444-459) or the sky; dispersed = false
@@ -1507,6 +1529,7 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
     }
 
     SLAP(sp, 2);
+    SYNC_PRIO(PYR_SYNC_PRIO_N);
     // next-event estimation gate, tracer.rs:257-280
     if (p.events < 2) {
         p.sample_light = !has_brdf || L.light_samples == 0;
@@ -1551,7 +1574,9 @@ DEV bool bounce_step(const DevScene& S, const RenderLaunch& L, const SceneView& 
                     const float limit = ls.sq_distance >= 0.0f ? ls.sq_distance - DIST_EPSILON : PYR_INF;
                     Hit shadow_hit;
                     SLAP(sp, 3);
+                    SYNC_PRIO(PYR_SYNC_PRIO_T);
                     const bool is_blocked = traverse<COUNT, true>(S, view.nodes, view.prims, position, ls.direction, limit, shadow_hit, stack, cnt);
+                    SYNC_PRIO(PYR_SYNC_PRIO_N);
                     SLAP(sp, 4);
                     if (is_blocked) continue;
                     uint32_t l_color = ls.color;
@@ -1688,6 +1713,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
             if (ended) break;
         }
         SLAP(sp, 6);
+        SYNC_PRIO(PYR_SYNC_PRIO_E);
         finish_path<COUNT>(launch_from_kernarg(L), p, spec, cnt);
         SLAP(sp, 7);
     }
@@ -2197,6 +2223,30 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
 // (rays are independent; they are served by a later turn). Must be called by every lane of the wave. Measured on C3
 // (intersect Mrays/s | stage-scheduled render Msamples/s): both kinds every turn 5774 | 210; minority runs too when it
 // has >= 16 lanes 5899 | 225; >= 32 lanes 5882 | 228; majority only (65) 6087 | 236.
+// Wave priority per phase of the stage scheduler (s_setprio, 0-3: a SIMD issues from the ready wave with the highest priority).
+// With equal priorities the arbiter interleaves a wave that walks the tree with one that replays tapes instruction by
+// instruction and both chains stretch; with the traversal on top, the replay (full width, no dependent fetches, the longest
+// phase) at the bottom and SHADE / NEE between them, every phase runs close to its own speed whenever it is ready and the
+// lower ones fill its waits: C3 533 -> 579 Msamples/s, C5 464 -> 507 (128 / 256 spp). Any split between traversal and the rest
+// gives +6 % -- in EITHER direction --, four distinct levels +8.5 %; the same priority per WAVE instead of per phase gives nothing.
+#ifndef PYR_PRIO_E
+#define PYR_PRIO_E 0
+#endif
+#ifndef PYR_PRIO_S
+#define PYR_PRIO_S 1
+#endif
+#ifndef PYR_PRIO_N
+#define PYR_PRIO_N 2
+#endif
+#ifndef PYR_PRIO_T
+#define PYR_PRIO_T 3
+#endif
+#define PYR_PRIO_ANY (PYR_PRIO_E != PYR_PRIO_S || PYR_PRIO_S != PYR_PRIO_N || PYR_PRIO_N != PYR_PRIO_T)
+#if PYR_PRIO_ANY
+#define PHASE_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PHASE_PRIO(x)
+#endif
 #ifndef PYR_VOTE_BOTH
 #define PYR_VOTE_BOTH 65
 #endif
@@ -3025,6 +3075,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
         if (max(max(nT, nS), max(nN, nE)) == 0) break; // every lane is DONE
 
         if (nE >= expose_lanes || nE == max(max(nT, nS), max(nN, nE))) {
+            PHASE_PRIO(PYR_PRIO_E);
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             const RenderLaunch& Lp = launch_from_kernarg(L);
             const DevScene Sp = scene_view(Lp);
@@ -3036,6 +3087,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             nE = 0;
         }
         if (nS >= phase_lanes || nS == max(max(nT, nS), max(nN, nE))) {
+            PHASE_PRIO(PYR_PRIO_S);
             PROF_BEGIN(1, w.stage == ST_SHADE);
             const RenderLaunch& Lp = launch_from_kernarg(L);
             w.shade(scene_view(Lp), Lp, spec, cnt);
@@ -3046,6 +3098,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             nS = 0;
         }
         if (nN >= phase_lanes || nN == max(max(nT, nS), max(nN, nE))) {
+            PHASE_PRIO(PYR_PRIO_N);
             PROF_BEGIN(2, w.stage == ST_NEE);
             const RenderLaunch& Lp = launch_from_kernarg(L);
             w.next_event(scene_view(Lp), Lp, spec, cnt);
@@ -3065,6 +3118,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
 #ifdef PYR_PHASE_PROFILE
             const unsigned long long prof_t0_3 = clock64();
 #endif
+            PHASE_PRIO(PYR_PRIO_T);
             w.t.inv = box_reciprocal(w.t.d); // 1 / direction for the box tests, live in this phase only
             trav_ray_signs(w.t);
             if (!LDS_SCENE && PYR_LEAN_STEP && !PYR_POSTPONE_LEAF && view.wide && view.pairs != nullptr) {
@@ -3388,6 +3442,7 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(D
 #ifndef PYR_INTERSECT_STEPS
 #define PYR_INTERSECT_STEPS 4
 #endif
+
 #ifndef PYR_INTERSECT_REFILL
 #define PYR_INTERSECT_REFILL 16
 #endif
