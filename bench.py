@@ -365,8 +365,8 @@ class Workload:
                                                     " (REDUCED: development run)" if self.reduced else ""),
             "bounces": r.bounces, "light_samples": r.light_samples, "spectrum_samples": r.spectrum_samples,
             "spectrum_bins": self.bins, "tile_size": r.tile_size, "triangles": len(self.world.flat.tri_material), "spheres": len(self.world.flat.spheres),
-            "parallelism": "one launch on one GPU" if world_size == 1 else "%s shares on %d GPUs (one launch per GPU), one film gather by %s"
-                           % (self.sharding, world_size, self.collective),
+            "parallelism": "one launch on one GPU" if world_size == 1 and getattr(self, "native", None) is None
+                           else "%s shares on %d GPUs (one launch per GPU), one film gather by %s" % (self.sharding, world_size, self.collective),
             # samples that map outside the image are dropped as in the reference (film.rs:51-54): a few per 1e7
             "film_weight": total_weight, "film_weight_expected": ("between %.0f and %.0f (dispersed paths expose the hero wavelength only)" % (samples, expected_weight))
             if dispersive else expected_weight,
@@ -430,6 +430,14 @@ def main():
     # PYRITE_BENCH_REHEARSAL=1 (development): all ranks share the visible GPUs and talk over gloo, to exercise the N > 1
     # code path on a one-GPU box; the line is marked and is not a measurement of anything.
     rehearsal = os.environ.get("PYRITE_BENCH_REHEARSAL") == "1"
+    # PYRITE_BENCH_FORCE_NATIVE=1 (development, one rank): walk the N > 1 branch below -- communicator, probe step, the steps
+    # through pyr_render_simple_sharded -- with a one-rank RCCL communicator, the only form of it a one-GPU box can run
+    force_native = os.environ.get("PYRITE_BENCH_FORCE_NATIVE") == "1" and world_size == 1
+    if force_native:
+        os.environ["PYRITE_FORCE_RCCL"] = "1"
+        os.environ.setdefault("PYRITE_SHARDING", "tiles")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
     if rehearsal:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -447,6 +455,10 @@ def main():
         if not rehearsal:
             torch.cuda.synchronize(device)
 
+    if force_native:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+
     def fence():
         if world_size > 1:
             dist.barrier()
@@ -455,7 +467,7 @@ def main():
     wl = Workload(args.workload, args, torch, local_rank, world_size, rehearsal)
     if rehearsal:
         wl.collective = "torch.distributed.gather over gloo (PYRITE_BENCH_REHEARSAL: ranks share the GPUs; not a measurement)"
-    if world_size > 1 and not rehearsal and wl.sharding == "tiles" and os.environ.get("PYRITE_BENCH_COLLECTIVE", "native") == "native":
+    if (world_size > 1 or force_native) and not rehearsal and wl.sharding == "tiles" and os.environ.get("PYRITE_BENCH_COLLECTIVE", "native") == "native":
         # The gather inside the library (pyr_render_simple_sharded: grouped ncclSend / ncclRecv). If the communicator cannot be
         # made on this node, every rank falls back TOGETHER to torch.distributed.gather over the same plan, and the line says so.
         from pyrite_amd import distributed as pdist
@@ -491,6 +503,8 @@ def main():
             if comm is not None:
                 comm.close()
             wl.collective = "torch.distributed.gather (RCCL); the native communicator failed on some rank%s" % (": " + why if why else "")
+        if force_native:
+            wl.collective += " -- PYRITE_BENCH_FORCE_NATIVE: one rank, a rehearsal of the code path"
     ms_per_step, film, seeds_used = timed_steps(wl, args.steps, args.warmup, args.seed, fence, dist, world_size)
     samples = wl.width * wl.height * wl.spp
     value = samples / (ms_per_step * 1e-3) / 1e6
@@ -566,6 +580,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world_size > 1:
         dist.barrier()  # rank 0 ran the instrumented pass above: leave together
+        dist.destroy_process_group()
+    elif force_native:
         dist.destroy_process_group()
     if mismatch:
         sys.exit("film weight check failed: the film does not hold samples x spectrum_samples exposures")

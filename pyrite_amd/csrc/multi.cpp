@@ -384,15 +384,26 @@ int pyr_render_simple_sharded(PyrComm* comm, PyrScene* scene, const PyrCamera* c
             auto note = [&](ncclResult_t r, const char* what) {
                 if (r != ncclSuccess && first == ncclSuccess) first = r, where = what;
             };
+            // One message per 256 MiB: RCCL 2.26.6 delivers about half of a single ncclSend / ncclRecv pair above 1 GiB (seen with
+            // the one-rank communicator at 1920 x 1080: 1.2 GB of blocks, rows 544-1079 never arrived, no error reported;
+            // tools/native_one_rank.py). Sends and receives between the same two ranks are matched in the order they are posted.
+            constexpr uint64_t kMessageFloats = 1ull << 26;
+            auto in_messages = [&](uint64_t floats, auto&& post) {
+                for (uint64_t done = 0; done < floats; done += kMessageFloats) post(done, std::min(kMessageFloats, floats - done));
+            };
             if (me == 0) {
                 uint64_t offset = 0;
                 for (uint32_t r = (n == 1 ? 0u : 1u); r < n; ++r) {
                     if (!grains[r]) continue;
-                    note(lib->Recv((PyrGrain*)comm->gathered.ptr + offset, (grains[r] + 1) * 2, ncclFloat, (int)r, comm->comm, stream), "ncclRecv");
+                    float* into = reinterpret_cast<float*>((PyrGrain*)comm->gathered.ptr + offset);
+                    in_messages((grains[r] + 1) * 2, [&](uint64_t at, uint64_t count) { note(lib->Recv(into + at, count, ncclFloat, (int)r, comm->comm, stream), "ncclRecv"); });
                     offset += grains[r] + 1;
                 }
             }
-            if ((me != 0 || n == 1) && grains[me]) note(lib->Send(comm->window.ptr, (grains[me] + 1) * 2, ncclFloat, 0, comm->comm, stream), "ncclSend");
+            if ((me != 0 || n == 1) && grains[me]) {
+                const float* from = reinterpret_cast<const float*>(comm->window.ptr);
+                in_messages((grains[me] + 1) * 2, [&](uint64_t at, uint64_t count) { note(lib->Send(from + at, count, ncclFloat, 0, comm->comm, stream), "ncclSend"); });
+            }
             note(lib->GroupEnd(), "ncclGroupEnd");
         }
         if (first != ncclSuccess) {

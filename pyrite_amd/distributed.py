@@ -142,7 +142,7 @@ def render_sharded(render_share, width, height, bins, tile_size, device, group=N
     """Runs `render_share(share, buffer)` once for this rank's share and gathers the film.
 
     `buffer` is a zeroed float32 [pixels, bins, 2] tensor on `device` laid out as the share says (Share.layout). Returns the
-    full film [height, width, bins, 2] on rank 0 and None elsewhere. Exactly one collective."""
+    full film [height, width, bins, 2] on rank 0 and None elsewhere. One gather (per 256 MiB of a share)."""
     world_size = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     shares = plan(width, height, tile_size, world_size, sharding)
@@ -166,7 +166,12 @@ def render_sharded(render_share, width, height, bins, tile_size, device, group=N
             gathered = [g.to(buffer.device) for g in gathered]
     else:
         gathered = [torch.empty_like(buffer) for _ in range(world_size)] if rank == 0 else None
-        dist.gather(buffer, gathered, dst=0, group=group)
+        # at most 256 MiB per message: RCCL 2.26.6 was seen to deliver half of a single send / receive pair above 1 GiB without
+        # an error (multi.cpp, tests/test_gpu_multi.py); C3's shares are below that from two ranks on, other films need not be
+        flat, limit = buffer.view(-1), 1 << 26
+        for at in range(0, flat.numel(), limit):
+            parts = [g.view(-1)[at:at + limit] for g in gathered] if rank == 0 else None
+            dist.gather(flat[at:at + limit], parts, dst=0, group=group)
     if rank != 0:
         return None
     film = torch.zeros((height, width, bins, 2), dtype=torch.float32, device=buffer.device)

@@ -51,6 +51,45 @@ def test_one_rank_rccl_communicator_gathers_through_send_and_recv(gpu_lib, monke
     world.close()
 
 
+def test_one_rank_rccl_gather_of_a_full_size_film_arrives_whole(gpu_lib, monkeypatch):
+    """1920 x 1080 = 2040 ringed tile blocks = 1.2 GB from one rank. Round 3 found that RCCL 2.26.6 delivers about half of a
+    single ncclSend / ncclRecv pair above 1 GiB and reports nothing (rows 544-1079 of the film stayed empty, the trailer word
+    behind them with it): pyr_render_simple_sharded posts one message per 256 MiB since. Everything on the device: the films
+    are compared there (1.06 GB each), and the launch-failure word must still arrive from behind the last block."""
+    import torch
+
+    from pyrite_amd import abi
+    from pyrite_amd import distributed as pdist
+    from pyrite_amd._lib import PyriteGpuError
+
+    monkeypatch.setenv("PYRITE_FORCE_RCCL", "1")
+    W, H = 1920, 1080
+    world, cam, r, _ = scenes.build(scenes.c3_mesh_in_box(W, H, 1, segments=32, sides=32), seed=2)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    desc = abi.PyrFilmDesc(W, H, r.spectrum_bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
+    plain = torch.zeros((H, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
+    r.render_device(plain.data_ptr(), desc, cam, world, stream=stream.cuda_stream, device=0)
+    comm = pdist.NativeSharded(0)
+    assert comm.uses_rccl
+    film = torch.zeros_like(plain)
+    comm.render(r, cam, world, desc, film, stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    comm.status()
+    assert float(plain[..., 1].sum(dtype=torch.float64)) >= 0.9999 * W * H * r.spectrum_samples
+    assert torch.equal(film[..., 1], plain[..., 1]), "part of the film never arrived"
+    assert torch.allclose(film[..., 0], plain[..., 0], rtol=1e-5, atol=0.0)
+    monkeypatch.setenv("PYRITE_TEST_FAIL_RENDER_RANK", "0")  # the trailer sits behind 1.2 GB of blocks: it must arrive too
+    film.zero_()
+    comm.render(r, cam, world, desc, film, stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    with pytest.raises(PyriteGpuError, match="could not launch"):
+        comm.status()
+    comm.close()
+    world.close()
+    del film, plain
+
+
 def test_one_rank_rccl_communicator_reports_a_film_the_kernels_flagged(gpu_lib, monkeypatch):
     """The error path through the real library: the spectral tape shrunk under its bound (PYRITE_TEST_TAPE_OPS) makes the
     kernels set their overflow word; it travels in the trailer through ncclSend / ncclRecv and pyr_comm_status reports it."""
