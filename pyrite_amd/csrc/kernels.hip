@@ -60,7 +60,7 @@ DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV f3 cross(f3 a, f3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DEV float magnitude(f3 a) { return sqrt32(dot(a, a)); }
 DEV f3 normalize_to(f3 a, float m) { return a * (m / magnitude(a)); } // cgmath: v * (m / |v|)
-DEV f3 normalize(f3 a) { return normalize_to(a, 1.0f); }
+DEV f3 normalize(f3 a) { return a * rcp32(magnitude(a)); } // normalize_to(a, 1.0f): 1.0f / |a| is a reciprocal (exact_math.h)
 DEV f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 
 // Transcendentals. The reference calls the platform libm through Rust's f32::sin / cos / acos; libms differ from one

@@ -19,3 +19,7 @@ def test_short_square_root_is_correctly_rounded_wherever_the_kernels_use_it(gpu_
     # identical for 0, -0, inf, NaN, negative and every positive argument above 4.6e-32; below that (the range the compiler's
     # expansion rescales for) it may be an ulp off -- squared lengths under 4.6e-32 are lengths under 2.2e-16
     assert r["sqrt_mismatches"] == 0 or (0.0 < r["sqrt_mismatch_lowest_abs"] and r["sqrt_mismatch_highest_abs"] <= 4.6e-32), r
+    # the short reciprocal (normalize: 1 / |v|): bit-identical to 1.0f / x for every x with 2^-126 <= |x| < 2^126, NaN stays NaN;
+    # zero, denormal, huge and infinite arguments are where it differs (exact_math.h says why the kernels never pass one)
+    assert r["rcp_inputs"] == 2 ** 32 and r["rcp_mismatches_in_range"] == 0, r
+    assert 0 < r["rcp_mismatches_outside"] <= 3 * 2 ** 24, r
