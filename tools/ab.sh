@@ -1,5 +1,5 @@
 #!/bin/bash
-# Developer tool (GPU box): A/B of library builds on the C3 (or C5) render, scene built per process, second render timed.
+# Developer tool (GPU box): A/B of library builds on the C3 (or C5) render, scene built per process, six renders, median of the last three.
 #   bash tools/ab.sh C3 128 main unsigned ...     ("main" = the in-tree library, other names = csrc/variants/lib_<name>.so)
 R=${GRAFT_REPO_ROOT:-$PWD}
 which=$1; spp=$2; shift 2
