@@ -68,6 +68,8 @@ def main():
         img = images.read_png(os.path.join(REFERENCE, name, "hq_example.png"))
         out[name] = block_means(img)
         out[name + "_size"] = np.array(img.shape[:2][::-1])
+        if name != "textures":  # round 4: the 8-bit values themselves, so that the transfer function that wrote them can be fitted
+            out[name + "_u8"] = np.ascontiguousarray(img[..., :3], dtype=np.uint8)  # (tests/reference_pin.py); expected outputs, data
         print(name, img.shape, "->", out[name].shape)
     np.savez_compressed(os.path.join(HERE, "reference_example_images.npz"), block=BLOCK, **out)
 
