@@ -432,13 +432,20 @@ void pyr_comm_destroy(PyrComm* comm);
  * to rank 0 (grouped ncclSend / ncclRecv: the one gather), and rank 0 adds everybody's blocks into `film_device_rank0` (a
  * whole-image film on rank 0's device; ignored on the other ranks, may be NULL there). `scene` must live on the
  * communicator's device. Working buffers are kept on the communicator between calls.
- *   Failures never leave a peer blocked (the reference's workers report to one collecting thread, renderer/mod.rs:181-183):
- * before anything is sent the ranks agree -- one one-word ncclAllReduce, waited for on the host -- that every rank got
+ *   Failures up to the gather never leave a peer blocked (the reference's workers report to one collecting thread,
+ * renderer/mod.rs:181-183): before anything is sent the ranks agree -- one one-word ncclAllReduce, waited for on the host -- that every rank got
  * through its argument checks and buffer growth; if one did not, EVERY rank returns an error and nothing is rendered. What
  * fails later (a launch, or the kernels flagging their own film invalid) travels in a trailer grain behind each rank's
  * blocks, so every rank still enters the gather; pyr_comm_status() reports it on rank 0 (every rank's trailer) and on the
  * sender (its own) once `hip_stream` has been waited for: PYR_OK, or PYR_ERR_DEVICE naming the rank -- the film is invalid
- * then. An error inside the collective calls aborts the communicator (ncclCommAbort); every later call on it fails. */
+ * then. An error inside the collective calls themselves aborts THIS rank's communicator (ncclCommAbort); every later call on
+ * it fails. pyr_render_simple_multi then aborts the sibling ranks' communicators too, at once, so none of its threads stays
+ * in the gather; ranks in OTHER processes cannot be reached from here -- their wait on `hip_stream` ends when RCCL notices
+ * the lost peer, so a multi-process caller should bound that wait.
+ *   Coordinates: the kernels' normalize / square root are the correctly rounded IEEE results (the reference's) for lengths whose
+ * squares are normal f32 numbers; pyr_scene_create refuses (PYR_ERR_UNSUPPORTED) a scene with a primitive beyond 1e15 units
+ * from the origin, and features below ~1e-15 units are outside the verified range (the reference itself ignores anything
+ * under DIST_EPSILON = 1e-4, math.rs:4). */
 int pyr_comm_status(PyrComm* comm);
 int pyr_render_simple_sharded(PyrComm* comm, PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film,
                               const PyrRenderParams* params, PyrGrain* film_device_rank0, void* hip_stream);

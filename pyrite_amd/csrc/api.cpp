@@ -17,6 +17,10 @@
 
 using namespace pyr;
 
+#ifndef PYR_QUANT_NODES
+#define PYR_QUANT_NODES 0
+#endif
+
 namespace {
 
 thread_local std::string g_error;
@@ -204,15 +208,10 @@ struct PyrScene {
     PyrCounters last_counters{};
     bool have_counters = false;
     uint32_t* tail_count = nullptr; // device, kFeedBytes: the work-feed cursors of the intersect kernel
-    // wavefront scheduler: path pool (grown on demand, kept between renders) and the pinned word the round loop polls
-    DeviceBuffer wf_stage, wf_groups, wf_companions, wf_words;
     DeviceBuffer tape; // spectral tape of the stage-scheduled kernel (grown on demand, kept between renders)
     DeviceBuffer tape_overflow; // one word the kernels set when a path outgrew the tape (checked after blocking renders and by pyr_scene_counters)
-    uint32_t wf_slots = 0, wf_companion_rows = 0;
-    uint32_t* wf_host_flag = nullptr;
     ~PyrScene() {
         if (tail_count) (void)hipFree(tail_count);
-        if (wf_host_flag) (void)hipHostFree(wf_host_flag);
     }
 };
 
@@ -294,6 +293,14 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         b.shape = ((uint32_t)PYR_SHAPE_TRIANGLE << 30) | i;
         bounds.push_back(b);
     }
+    // exact_math.h: `normalize` multiplies by rcp32(sqrt32(|v|^2)), which is the correctly rounded IEEE result (what the reference
+    // computes) only while lengths and squared lengths stay normal f32 numbers. Coordinates are the user's units, so a scene whose
+    // extent leaves the verified range is refused instead of rendered differently from the reference (pyrite_gpu.h "Coordinates").
+    constexpr float kMaxCoordinate = 1.0e15f;
+    for (const PrimBounds& b : bounds)
+        for (int a = 0; a < 3; ++a)
+            if (!(std::fabs(b.lo[a]) <= kMaxCoordinate && std::fabs(b.hi[a]) <= kMaxCoordinate))
+                return fail(PYR_ERR_UNSUPPORTED, "a primitive lies beyond 1e15 units from the origin (or is not finite): outside the range the kernels' arithmetic is verified for");
     // Leaves are tested in pairs only by the four-child pair tree: a triangle-only scene too big to live in LDS (its
     // primitives alone outgrow the 8 KB the LDS-resident walk allows) with neither tree switched off.
     const char* wide_switch = std::getenv("PYRITE_WIDE_BVH");
@@ -477,8 +484,16 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             }
     }
     if ((rc = s->pair_prims.upload(pairs.data(), pairs.size() * sizeof(DevPrimPair)))) return rc;
+#if PYR_QUANT_NODES // A/B build (bvh.h NodeQ64): both copies of the wide tree as 64-byte quantized nodes, same indices
+    {
+        const std::vector<NodeQ64> qp = quantize_wide(pair_nodes), qw = quantize_wide(wide.nodes);
+        if ((rc = s->wide_pair_nodes.upload(qp.data(), qp.size() * sizeof(NodeQ64)))) return rc;
+        if ((rc = s->wide_nodes.upload(qw.data(), qw.size() * sizeof(NodeQ64)))) return rc;
+    }
+#else
     if ((rc = s->wide_pair_nodes.upload(pair_nodes.data(), pair_nodes.size() * sizeof(Node128)))) return rc;
     if ((rc = s->wide_nodes.upload(wide.nodes.data(), wide.nodes.size() * sizeof(Node128)))) return rc;
+#endif
     if ((rc = s->prims.upload(prims.data(), prims.size() * sizeof(DevPrim)))) return rc;
     if ((rc = s->tri_shade.upload(shade.data(), shade.size() * sizeof(DevTriShade)))) return rc;
     if ((rc = s->spheres.upload(d->spheres, (size_t)d->num_spheres * 16))) return rc;
@@ -615,41 +630,6 @@ int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
 // Scheduler choice (kernels.hip): the bounce-synchronous walk wins when the scene lives in LDS and traversal is cheap
 // (C2: 573 vs 300 Msamples/s); the stage scheduler wins when traversal lengths are heavy tailed (C3: 110 vs 91).
 // PYRITE_SCHEDULER=sync|sm overrides; PYRITE_SM_LANES / PYRITE_SM_STEPS tune the stage scheduler.
-// Path pool of the wavefront scheduler: one slot per lane of `waves` virtual waves, at most PYRITE_WF_SLOTS (default 4 Mi)
-// slots = 1.3 GB at 10 spectrum samples. Kept on the scene between renders, regrown when a render needs more.
-int wavefront_pool(PyrScene* scene, const RenderLaunch& L, WfPool& pool) {
-    const char* e = std::getenv("PYRITE_WF_SLOTS");
-    uint64_t max_slots = e && *e ? std::strtoull(e, nullptr, 10) : (16ull << 20);
-    max_slots = std::max<uint64_t>(64, max_slots & ~63ull);
-    const uint64_t chunks = L.chunk_end - L.chunk_begin;
-    const uint32_t slots = (uint32_t)std::min<uint64_t>(chunks * 64ull, max_slots);
-    const uint32_t rows = 3 * (L.spectrum_samples - 1);
-    if (slots > scene->wf_slots || rows > scene->wf_companion_rows) {
-        scene->wf_stage.release();
-        scene->wf_groups.release();
-        scene->wf_companions.release();
-        const uint32_t cap = std::max(slots, scene->wf_slots), cap_rows = std::max(rows, scene->wf_companion_rows);
-        scene->wf_slots = scene->wf_companion_rows = 0;
-        int rc;
-        if ((rc = scene->wf_stage.alloc((size_t)cap * sizeof(uint32_t))) != PYR_OK) return rc;
-        if ((rc = scene->wf_groups.alloc((size_t)cap * kWfStateGroups * 16)) != PYR_OK) return rc;
-        if ((rc = scene->wf_companions.alloc((size_t)cap * std::max(cap_rows, 1u) * sizeof(float))) != PYR_OK) return rc;
-        scene->wf_slots = cap;
-        scene->wf_companion_rows = cap_rows;
-    }
-    if (!scene->wf_words.ptr) {
-        int rc = scene->wf_words.alloc(kFeedBytes + sizeof(uint32_t));
-        if (rc != PYR_OK) return rc;
-    }
-    if (!scene->wf_host_flag) HIP_TRY(hipHostMalloc((void**)&scene->wf_host_flag, sizeof(uint32_t)));
-    pool.n = slots;
-    pool.stage = (uint32_t*)scene->wf_stage.ptr;
-    pool.groups = (float*)scene->wf_groups.ptr;
-    pool.companions = (float*)scene->wf_companions.ptr;
-    pool.next = (uint32_t*)scene->wf_words.ptr;
-    pool.work_flag = (uint32_t*)scene->wf_words.ptr + kFeedSegments * kFeedCursorStride;
-    return PYR_OK;
-}
 
 // The spectral tape ([tape_max_ops][tape_lanes] 8-byte records) and the overflow word, kept on the scene between renders.
 int reserve_tape(PyrScene* scene, RenderLaunch& L, hipStream_t stream) {
@@ -679,36 +659,19 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 1;
     else if (e && std::string(e) == "sync")
         L.scheduler = 0;
-    else if (e && std::string(e) == "wf")
-        L.scheduler = 2;
-    else if (e && std::string(e) == "split")
-        L.scheduler = 3;
     else // the synchronous walk for scenes that live in LDS -- unless they run interpreter programs: the stage scheduler keeps the
          // interpreter in line and memoised (spheres example 572 -> 737, lamps 549 -> 724 Msamples/s against the synchronous walk)
         L.scheduler = scene_is_lds_resident(scene->dev) && scene->dev.needs_interpreter == 0 ? 0u : 1u;
     // the program interpreter (and with it texture coordinates and normal maps) lives in the resumable integrator (Walker), in
     // line; the synchronous walk is built without it: PYRITE_SCHEDULER=sync on such a scene runs the stage scheduler
     if (L.scheduler == 0 && scene->dev.needs_interpreter != 0) L.scheduler = 1;
-    if (L.scheduler == 2) {
-        WfPool pool{};
-        int rc = wavefront_pool(scene, L, pool);
-        if (rc != PYR_OK) return rc;
-        if (wavefront_uses_tape(scene->dev, L)) { // one tape column per pool slot
-            L.tape_lanes = pool.n;
-            L.tape_max_ops = tape_ops_bound(L);
-            if ((rc = reserve_tape(scene, L, stream)) != PYR_OK) return rc;
-        }
-        rc = launch_wavefront(scene->dev, L, count, stream, scene->num_cus, pool, scene->wf_host_flag);
-        if (rc != PYR_OK) return fail(rc, kernels_last_error());
-        return PYR_OK;
-    }
     const char* lanes = std::getenv("PYRITE_SM_LANES");
     const char* steps = std::getenv("PYRITE_SM_STEPS");
     L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;
-    if ((L.scheduler == 1 || L.scheduler == 3) && scene->dev.needs_interpreter == 0) {
+    if (L.scheduler == 1 && scene->dev.needs_interpreter == 0) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
         L.tape_max_ops = tape_ops_bound(L);
         int rc = reserve_tape(scene, L, stream);
@@ -726,7 +689,7 @@ int check_tape_overflow(PyrScene* scene) {
     HIP_TRY(hipMemcpy(&word, scene->tape_overflow.ptr, sizeof(word), hipMemcpyDeviceToHost));
     if (word == 0) return PYR_OK;
     HIP_TRY(hipMemset(scene->tape_overflow.ptr, 0, sizeof(uint32_t)));
-    if (word == 2) return fail(PYR_ERR_DEVICE, "the split scheduler gave up waiting (a wave polled its LDS slots past the spin limit): the film of that render is invalid");
+    if (word == 2) return fail(PYR_ERR_DEVICE, "a wave gave up waiting on its workgroup's LDS queues (spin limit): the film of that render is invalid");
     return fail(PYR_ERR_DEVICE, "a path appended more records than the spectral tape's bound allows: the film of that render is invalid");
 }
 

@@ -137,7 +137,7 @@ struct RenderLaunch {
     float grains_per_wavelength; // bins / wl_width (film.rs:38)
     PyrGrain* film_out;
     unsigned long long* counters; // 9 words (PyrCounters order) or nullptr
-    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm), 2 = wavefront, 3 = split (render_kernel_split)
+    uint32_t scheduler; // 0 = bounce-synchronous walk (render_kernel), 1 = stage-scheduled state machine (render_kernel_sm)
     uint32_t sm_phase_lanes, sm_trav_steps; // stage scheduler: lanes that make a phase run; traversal steps per turn
     uint32_t sm_expose_lanes;               // finished lanes that make the tape replay run (TAPE builds)
     uint32_t stack_lds; // traversal stack levels kept in LDS (set by launch_render; deeper levels spill to scratch in the sm kernel)
@@ -148,17 +148,6 @@ struct RenderLaunch {
     uint32_t* tape_overflow; // device word, set when a path wanted to append more than tape_max_ops records
     uint32_t tape_programs_lds; // programs whose prepared form the kernel keeps in LDS for the replay (set by launch_render; 0 = none)
 };
-
-// Path pool of the wavefront scheduler (kernels.hip "Wavefront integrator"): n slots, all arrays [field][slot].
-struct WfPool {
-    uint32_t n;          // slots, a multiple of 64
-    uint32_t* stage;     // [n] stage word
-    float* groups;       // [kWfStateGroups][n] float4
-    float* companions;   // [3 * (spectrum_samples - 1)][n]
-    uint32_t* next;      // device: work-feed cursors of the traversal kernel (kFeedBytes)
-    uint32_t* work_flag; // device word: set by the logic kernel while any path still needs a ray
-};
-constexpr uint32_t kWfStateGroups = 12;
 
 // Work feed of the persistent traversal kernels: kFeedSegments cursor words, kFeedCursorStride words apart (kernels.hip WorkFeed).
 constexpr uint32_t kFeedSegments = 8, kFeedCursorStride = 64;
@@ -205,11 +194,6 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_c
 uint32_t tape_ops_bound(const RenderLaunch& launch); // records per path the stage-scheduled kernel may append to its spectral tape
 uint32_t tape_lanes_bound(int num_cus);              // lanes (tape columns) of the largest grid launch_render starts
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);
-// Wavefront render: alternates the logic and traversal kernels until every path of the launch has ended. Blocks on `stream`
-// (the loop's end is decided by the device). `host_flag` is one pinned host word.
-int launch_wavefront(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus, const WfPool& pool,
-                     volatile uint32_t* host_flag);
-bool wavefront_uses_tape(const DevScene& scene, const RenderLaunch& launch); // the wavefront logic kernel records a tape for this launch
 const char* kernels_last_error();
 bool scene_is_lds_resident(const DevScene& scene);
 

@@ -1763,8 +1763,7 @@ __global__ __launch_bounds__(BLOCK, 4) void render_kernel(DevScene S0, RenderLau
 #define PROF_FLUSH()
 #endif
 
-enum Touched : uint32_t { TOUCH_NEW = 1, TOUCH_BRIGHT = 2, TOUCH_REFL = 4, TOUCH_SHADE = 8, TOUCH_LIGHT = 16 };
-enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EXPOSE = 4, ST_DONE = 5, ST_WAIT = 6 }; // ST_WAIT: render_kernel_split, the ray is with a traversal wave
+enum Stage : uint32_t { ST_NEW = 0, ST_TRAV = 1, ST_SHADE = 2, ST_NEE = 3, ST_EXPOSE = 4, ST_DONE = 5 };
 
 struct Trav { // resumable World::intersect
     f3 o, d, inv;
@@ -1780,9 +1779,7 @@ struct Trav { // resumable World::intersect
     uint32_t shape;
     float u, v;
     bool shadow, blocked;
-    int parked = 0; // trav_step_postponed: the code of a leaf the lane has walked into and not tested yet (0: none)
 };
-constexpr int kNoNode = INT32_MIN; // trav_step_postponed: t.node when the lane holds no subtree any more (never a leaf code: api.cpp keeps first + count < 2^28)
 
 DEV void trav_ray_signs(Trav& t) {
     t.nx = (__float_as_uint(t.d.x) >> 31) * 48u;
@@ -1799,7 +1796,6 @@ DEV void trav_restart(Trav& t) {
     t.blocked = false;
     t.node = 0;
     t.sp = 0;
-    t.parked = 0;
 }
 
 // Planes first (world.rs:277-285), then the tree from the root. Returns true when the query is already decided.
@@ -1908,27 +1904,6 @@ DEV void wide_node_children(const float4 lx, const float4 ly, const float4 lz, c
     order(1, 3);
     order(1, 2);
 }
-template <bool COUNT, bool POSTPONE = false, bool SIGNED = false>
-DEV bool wide_node_visit(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, const float4 ch, Trav& t,
-                         TravStack& stack, Counters& cnt) {
-    float e[4];
-    int c[4];
-    wide_node_children<COUNT, SIGNED>(lx, ly, lz, hx, hy, hz, ch, t, cnt, e, c);
-    if (c[0] == INT32_MIN) { // nothing hit
-        if (t.sp == 0) {
-            if (POSTPONE) t.node = kNoNode;
-            return true;
-        }
-        t.sp--;
-        t.node = stack.pop(t.sp);
-        return false;
-    }
-    if (c[3] != INT32_MIN) stack.push(t.sp++, c[3]);
-    if (c[2] != INT32_MIN) stack.push(t.sp++, c[2]);
-    if (c[1] != INT32_MIN) stack.push(t.sp++, c[1]);
-    t.node = c[0];
-    return false;
-}
 // GLOBAL says the scene pointers are known to point into device memory (everything but a scene staged in LDS): the loads
 // are then global_load, not flat_load (own_scalar's result is an integer to the compiler, so the address space is stated here).
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -1960,10 +1935,89 @@ DEV WidePlanes load_wide_planes(const float4* wide_nodes, const Trav& t) {
     const uint32_t ax = base + t.nx, ay = base + t.ny, az = base + t.nz;
     return WidePlanes{plane(ax), plane(ay + 16u), plane(az + 32u), plane(ax ^ 48u), plane((ay ^ 48u) + 16u), plane((az ^ 48u) + 32u), plane(base + 96u)};
 }
-template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
+#ifndef PYR_QUANT_NODES
+#define PYR_QUANT_NODES 0
+#endif
+// The box tests of one visit of a QUANTIZED four-child node (bvh.h NodeQ64, -DPYR_QUANT_NODES=1): four loads instead of seven.
+// Every plane is origin + scale * byte, so its distance along the ray is byte * (scale * inv) + (origin - o) * inv: one
+// v_cvt_f32_ubyteN and one (packed) fma per plane. Near / far planes by the ray's signs as in load_wide_planes, here a select
+// between the lo and hi dwords. Same outputs as wide_node_children: c[] the children that are hit, nearest first, e[] their
+// entry distances, INT32_MIN / +inf at the end.
+template <bool COUNT>
+DEV void wide_children_quantized(const float4* wide_nodes, const Trav& t, Counters& cnt, float (&e)[4], int (&c)[4]) {
+    const char* nodes = reinterpret_cast<const char*>(wide_nodes);
+    auto vec = [&](uint32_t byte_offset) { return *(global_f4v*)(nodes + byte_offset); };
+    const uint32_t base = (uint32_t)t.node << 6;
+    const f4v v0 = vec(base), v1 = vec(base + 16u), v2 = vec(base + 32u), v3 = vec(base + 48u);
+    const float ax = v0.w * t.inv.x, ay = v1.x * t.inv.y, az = v1.y * t.inv.z;
+    const float bx = (v0.x - t.o.x) * t.inv.x, by = (v0.y - t.o.y) * t.inv.y, bz = (v0.z - t.o.z) * t.inv.z;
+    const uint32_t lox = __float_as_uint(v1.z), loy = __float_as_uint(v1.w), loz = __float_as_uint(v2.x);
+    const uint32_t hix = __float_as_uint(v2.y), hiy = __float_as_uint(v2.z), hiz = __float_as_uint(v2.w);
+    const bool negx = t.nx != 0u, negy = t.ny != 0u, negz = t.nz != 0u; // trav_ray_signs: non-zero for a negative direction component
+    const uint32_t nearx = negx ? hix : lox, farx = negx ? lox : hix;
+    const uint32_t neary = negy ? hiy : loy, fary = negy ? loy : hiy;
+    const uint32_t nearz = negz ? hiz : loz, farz = negz ? loz : hiz;
+    c[0] = __float_as_int(v3.x), c[1] = __float_as_int(v3.y), c[2] = __float_as_int(v3.z), c[3] = __float_as_int(v3.w);
+    const f2v pax = {ax, ax}, pay = {ay, ay}, paz = {az, az}, pbx = {bx, bx}, pby = {by, by}, pbz = {bz, bz};
+    auto b0 = [](uint32_t w) { return (float)(w & 0xffu); };
+    auto b1 = [](uint32_t w) { return (float)((w >> 8) & 0xffu); };
+    auto b2 = [](uint32_t w) { return (float)((w >> 16) & 0xffu); };
+    auto b3 = [](uint32_t w) { return (float)(w >> 24); };
+    const f2v nx01 = __builtin_elementwise_fma((f2v){b0(nearx), b1(nearx)}, pax, pbx), nx23 = __builtin_elementwise_fma((f2v){b2(nearx), b3(nearx)}, pax, pbx);
+    const f2v ny01 = __builtin_elementwise_fma((f2v){b0(neary), b1(neary)}, pay, pby), ny23 = __builtin_elementwise_fma((f2v){b2(neary), b3(neary)}, pay, pby);
+    const f2v nz01 = __builtin_elementwise_fma((f2v){b0(nearz), b1(nearz)}, paz, pbz), nz23 = __builtin_elementwise_fma((f2v){b2(nearz), b3(nearz)}, paz, pbz);
+    const f2v fx01 = __builtin_elementwise_fma((f2v){b0(farx), b1(farx)}, pax, pbx), fx23 = __builtin_elementwise_fma((f2v){b2(farx), b3(farx)}, pax, pbx);
+    const f2v fy01 = __builtin_elementwise_fma((f2v){b0(fary), b1(fary)}, pay, pby), fy23 = __builtin_elementwise_fma((f2v){b2(fary), b3(fary)}, pay, pby);
+    const f2v fz01 = __builtin_elementwise_fma((f2v){b0(farz), b1(farz)}, paz, pbz), fz23 = __builtin_elementwise_fma((f2v){b2(farz), b3(farz)}, paz, pbz);
+    const float tn[4][3] = {{nx01.x, ny01.x, nz01.x}, {nx01.y, ny01.y, nz01.y}, {nx23.x, ny23.x, nz23.x}, {nx23.y, ny23.y, nz23.y}};
+    const float tf[4][3] = {{fx01.x, fy01.x, fz01.x}, {fx01.y, fy01.y, fz01.y}, {fx23.x, fy23.x, fz23.x}, {fx23.y, fy23.y, fz23.y}};
+    for (int k = 0; k < 4; ++k) {
+        const float tmin = fmaxf(fmaxf(tn[k][0], tn[k][1]), tn[k][2]);
+        const float tmax = fminf(fminf(tf[k][0], tf[k][1]), tf[k][2]);
+        const float entry = fmaxf(tmin, 0.0f);
+        if (COUNT) cnt.box_tests += c[k] != INT32_MIN ? 1u : 0u;
+        const bool hit = (tmax >= entry) & (entry < t.closest) & (c[k] != INT32_MIN); // an unused slot's inverted box is not one on an axis where the node is flat
+        e[k] = hit ? entry : PYR_INF;
+        c[k] = hit ? c[k] : INT32_MIN;
+    }
+    auto order = [&](int a, int b) {
+        const bool sw = e[b] < e[a];
+        const float ea = sw ? e[b] : e[a], eb = sw ? e[a] : e[b];
+        const int ca = sw ? c[b] : c[a], cb = sw ? c[a] : c[b];
+        e[a] = ea, e[b] = eb, c[a] = ca, c[b] = cb;
+    };
+    order(0, 1);
+    order(2, 3);
+    order(0, 2);
+    order(1, 3);
+    order(1, 2);
+}
+// c[] / e[] of the node a lane stands at, whichever node format the library is built for.
+template <bool COUNT>
+DEV void wide_children(const float4* wide_nodes, const Trav& t, Counters& cnt, float (&e)[4], int (&c)[4]) {
+#if PYR_QUANT_NODES
+    wide_children_quantized<COUNT>(wide_nodes, t, cnt, e, c);
+#else
+    const WidePlanes pl = load_wide_planes(wide_nodes, t); // near / far planes picked by the ray's signs (trav_ray_signs)
+    wide_node_children<COUNT, true>(pl.nx, pl.ny, pl.nz, pl.fx, pl.fy, pl.fz, pl.ch, t, cnt, e, c);
+#endif
+}
+template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    const WidePlanes n = load_wide_planes(view.nodes, t);
-    return wide_node_visit<COUNT, POSTPONE, true>(n.nx, n.ny, n.nz, n.fx, n.fy, n.fz, n.ch, t, stack, cnt);
+    float e[4];
+    int c[4];
+    wide_children<COUNT>(view.nodes, t, cnt, e, c);
+    if (c[0] == INT32_MIN) { // nothing hit
+        if (t.sp == 0) return true;
+        t.sp--;
+        t.node = stack.pop(t.sp);
+        return false;
+    }
+    if (c[3] != INT32_MIN) stack.push(t.sp++, c[3]);
+    if (c[2] != INT32_MIN) stack.push(t.sp++, c[2]);
+    if (c[1] != INT32_MIN) stack.push(t.sp++, c[1]);
+    t.node = c[0];
+    return false;
 }
 
 // One primitive of a leaf, its record already loaded (a, b, c = the three vectors of a DevPrim): the tests and the
@@ -2007,45 +2061,6 @@ DEV bool leaf_prim_visit(const float4 a, const float4 b, const float4 c, uint32_
     t.sp--;
     t.node = stack.pop(t.sp);
     return false;
-}
-
-// One step of every lane that has a ray in flight, whichever kind it waits for, on ONE memory round trip: a lane at an inner
-// node needs the node's seven vectors, a lane in a leaf the primitive's three; all lanes issue their first three loads
-// together (the address differs, the instruction is the same), the node lanes their other four right behind, and only then
-// does anybody wait. The node arithmetic and the primitive test still run one after the other at partial occupancy, but the
-// round trip -- which is what a step costs (21.9 k cycles per 8-step turn on C3 against ~600 cycles of issue) -- is paid once
-// per step instead of once per kind, and no lane sits a step out as under the node / leaf vote. Wide trees only.
-template <bool COUNT, bool GLOBAL = true>
-DEV bool trav_step_unified(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
-    const bool at_node = active && t.node >= 0;
-    const uint32_t code = (uint32_t)(-1 - t.node);
-    const uint32_t first = code >> 3, count = code & 7u;
-    const bool at_prim = active && t.node < 0 && count != 0;
-    const ScenePtr<GLOBAL> addr{at_node ? view.nodes + 8 * (size_t)t.node : view.prims + 3 * (size_t)first};
-    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0;
-    if (at_node || at_prim) {
-        r0 = addr[0];
-        r1 = addr[1];
-        r2 = addr[2];
-    }
-    if (at_node) {
-        r3 = addr[3];
-        r4 = addr[4];
-        r5 = addr[5];
-        r6 = addr[6];
-    }
-    bool done = false;
-    if (at_node) done = wide_node_visit<COUNT>(r0, r1, r2, r3, r4, r5, r6, t, stack, cnt);
-    if (at_prim) done = leaf_prim_visit<COUNT>(r0, r1, r2, first, count, t, stack, cnt);
-    if (active && !at_node && !at_prim) { // an empty leaf: nothing to test
-        if (t.sp == 0) {
-            done = true;
-        } else {
-            t.sp--;
-            t.node = stack.pop(t.sp);
-        }
-    }
-    return done;
 }
 
 // An inner-node visit of a lane whose t.node >= 0. Returns true when the traversal has finished.
@@ -2146,65 +2161,6 @@ DEV bool trav_leaf_step(const SceneView& view, Trav& t, TravStack& stack, Counte
     t.node = stack.pop(t.sp);
     return false;
 }
-template <bool COUNT, bool GLOBAL = true>
-DEV bool trav_step(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
-    return t.node >= 0 ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : trav_leaf_step<COUNT, GLOBAL>(view, t, stack, cnt);
-}
-
-// The vote of trav_step_voted leaves the lanes of the other kind idle for the step. Here a lane that walks into a leaf parks
-// the leaf (t.parked) and goes on with the next subtree on its stack, so it takes part in the node steps until it walks into a
-// second leaf, and the leaf step finds the lanes that have parked one in the meantime (speculative traversal in the sense of
-// Aila & Laine 2009). The boxes visited while a leaf is parked are tested against the closest hit the leaf has not improved
-// yet: a few more node visits, no other result -- the closest hit is a minimum and a shadow ray's verdict an `or`, whatever
-// the order (equal distances excepted: the first one found keeps the hit, as everywhere). Wide trees only.
-#ifndef PYR_LEAF_WEIGHT
-#define PYR_LEAF_WEIGHT 100 // the leaf step runs when lanes_with_a_parked_leaf * 100 >= lanes_at_a_node * PYR_LEAF_WEIGHT
-#endif
-template <bool COUNT>
-DEV bool trav_step_postponed(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
-    if (active && t.node < 0 && t.node != kNoNode && t.parked == 0) {
-        t.parked = t.node;
-        if (t.sp == 0) {
-            t.node = kNoNode;
-        } else {
-            t.sp--;
-            t.node = stack.pop(t.sp);
-        }
-    }
-    const bool want_node = active && t.node >= 0, want_leaf = active && t.parked != 0;
-    const int n_node = __popcll(ballot64(want_node)), n_leaf = __popcll(ballot64(want_leaf));
-    if (n_leaf * 100 >= n_node * PYR_LEAF_WEIGHT) {
-        if (want_leaf) {
-            const uint32_t code = (uint32_t)(-1 - t.parked);
-            const uint32_t first = code >> 3, count = code & 7u;
-            bool blocks = false;
-            uint32_t left = 0;
-            if (view.pairs != nullptr) {
-                if (count != 0) {
-                    const ScenePtr<true> pr{view.pairs + 5 * (size_t)first};
-                    blocks = leaf_pair_test<COUNT>(pr[0], pr[1], pr[2], pr[3], pr[4], count, t, cnt);
-                }
-                left = count > 2u ? count - 2u : 0u;
-            } else {
-                if (count != 0) {
-                    const ScenePtr<true> pr{view.prims + 3 * (size_t)first};
-                    blocks = leaf_prim_test<COUNT>(pr[0], pr[1], pr[2], t, cnt);
-                }
-                left = count > 1u ? count - 1u : 0u;
-            }
-            t.parked = left != 0 ? -1 - (int)(((first + 1u) << 3) | left) : 0;
-            if (blocks) {
-                t.parked = 0;
-                t.node = kNoNode;
-                t.sp = 0;
-            }
-        }
-    } else if (want_node) {
-        trav_step_wide<COUNT, true, true>(view, t, stack, cnt);
-    }
-    return active && t.node == kNoNode && t.parked == 0;
-}
-
 // The step of trav_step_voted (majority kind only) for the tree the big scenes walk -- four-child nodes whose leaves index
 // triangle pairs -- as straight-line code. What the generic step spends around the tests is control flow: three conditional
 // pushes, each an LDS-or-scratch choice (two saved exec masks and their branches per push), the same again around the pop, and
@@ -2218,11 +2174,10 @@ DEV bool trav_step_postponed(const SceneView& view, Trav& t, TravStack& stack, C
 template <bool COUNT>
 DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active);
 // One step for the lanes of a wave that have a ray in flight (`active`), with a vote: a step is an inner-node visit or a
-// primitive test, two different pieces of code, and a wave whose lanes want both runs both at partial occupancy. When fewer
-// than PYR_VOTE_BOTH lanes want the minority kind, only the majority kind runs this turn and the minority keeps its place
-// (rays are independent; they are served by a later turn). Must be called by every lane of the wave. Measured on C3
-// (intersect Mrays/s | stage-scheduled render Msamples/s): both kinds every turn 5774 | 210; minority runs too when it
-// has >= 16 lanes 5899 | 225; >= 32 lanes 5882 | 228; majority only (65) 6087 | 236.
+// primitive test, two different pieces of code, and a wave whose lanes want both runs both at partial occupancy. Only the
+// kind most lanes wait for runs this turn; the minority keeps its place (rays are independent; a later turn serves them).
+// Must be called by every lane of the wave. Measured on C3 (intersect Mrays/s | stage-scheduled render Msamples/s): both kinds
+// every turn 5774 | 210; minority too when it has >= 16 / 32 lanes 5899 | 225, 5882 | 228; majority only 6087 | 236.
 // Wave priority per phase of the stage scheduler (s_setprio, 0-3: a SIMD issues from the ready wave with the highest priority).
 // With equal priorities the arbiter interleaves a wave that walks the tree with one that replays tapes instruction by
 // instruction and both chains stretch; with the traversal on top, the replay (full width, no dependent fetches, the longest
@@ -2247,38 +2202,13 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
 #else
 #define PHASE_PRIO(x)
 #endif
-#ifndef PYR_VOTE_BOTH
-#define PYR_VOTE_BOTH 65
-#endif
-#ifndef PYR_UNIFIED_FETCH
-#define PYR_UNIFIED_FETCH 0
-#endif
-#ifndef PYR_POSTPONE_LEAF
-#define PYR_POSTPONE_LEAF 0
-#endif
-#ifndef PYR_LEAN_STEP
-#define PYR_LEAN_STEP 1
-#endif
-template <bool COUNT, bool GLOBAL = true, bool POSTPONE = false>
+template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_voted(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt, bool active) {
-    if constexpr (POSTPONE && GLOBAL) {
-        if (view.wide) return trav_step_postponed<COUNT>(view, t, stack, cnt, active);
-    }
-    if (PYR_UNIFIED_FETCH && view.wide && view.pairs == nullptr) return trav_step_unified<COUNT, GLOBAL>(view, t, stack, cnt, active);
     const bool at_node = t.node >= 0;
     const unsigned long long nodes = ballot64(active && at_node), leaves = ballot64(active && !at_node);
-    if (PYR_VOTE_BOTH > 64) {
-        // majority only: the choice is wave-uniform, so it is a scalar branch to ONE of the two bodies, not two masked regions
-        if (__popcll(nodes) >= __popcll(leaves)) return (active && at_node) ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
-        return (active && !at_node) ? trav_leaf_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
-    }
-    if (PYR_VOTE_BOTH > 0) {
-        const int want_node = __popcll(nodes), want_leaf = __popcll(leaves);
-        const bool run_node = want_node >= want_leaf || want_node >= PYR_VOTE_BOTH;
-        const bool run_leaf = want_leaf > want_node || want_leaf >= PYR_VOTE_BOTH;
-        if (active && !(at_node ? run_node : run_leaf)) active = false;
-    }
-    return active && trav_step<COUNT, GLOBAL>(view, t, stack, cnt);
+    // the choice is wave-uniform, so it is a scalar branch to ONE of the two bodies, not two masked regions
+    if (__popcll(nodes) >= __popcll(leaves)) return (active && at_node) ? trav_node_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
+    return (active && !at_node) ? trav_leaf_step<COUNT, GLOBAL>(view, t, stack, cnt) : false;
 }
 
 template <bool COUNT>
@@ -2303,8 +2233,7 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
             const int top = stack.lds[below * BLOCK];
             float e[4];
             int c[4];
-            const WidePlanes pl = load_wide_planes(view.nodes, t); // near / far planes picked by the ray's signs (trav_ray_signs)
-            wide_node_children<COUNT, true>(pl.nx, pl.ny, pl.nz, pl.fx, pl.fy, pl.fz, pl.ch, t, cnt, e, c);
+            wide_children<COUNT>(view.nodes, t, cnt, e, c);
             const bool none = c[0] == INT32_MIN, hit1 = c[1] != INT32_MIN, hit2 = c[2] != INT32_MIN, hit3 = c[3] != INT32_MIN;
             const int n = (hit1 ? 1 : 0) + (hit2 ? 1 : 0) + (hit3 ? 1 : 0); // children to push: c[1 .. n], far to near
             const int above = t.sp + n;
@@ -2414,8 +2343,6 @@ struct Walker {
     f3 ls_normal = mk(0, 0, 0);
     float ls_scale = 0.0f;
     float ls_tx = 0.0f, ls_ty = 0.0f; // its texture coordinates (interpreter builds)
-    // what this visit changed, for schedulers that keep the state in memory between phases (dead code elsewhere)
-    uint32_t touched = 0;
 
     // Interpreter builds (INTERP, no tape): what `contribute` (renderer/algorithm.rs:14-100) is to be applied to by the phase
     // that has just run -- at most one program evaluation (a bounce's colour, an emission / sky / light-sample addition) and
@@ -2495,12 +2422,10 @@ struct Walker {
                 tape_push(L, TAPE_SCALE, 0u, brdf);
             } else if constexpr (INTERP) {
                 c_scale = brdf, c_has_scale = true; // behind this turn's contribution (contribute_pending)
-                if (p.use_additional) touched |= TOUCH_REFL;
             } else {
                 p.refl *= brdf;
                 if (p.use_additional) {
                     for (uint32_t k = 0; k < n_add; ++k) spec.refl(k) *= brdf;
-                    touched |= TOUCH_REFL;
                 }
             }
         }
@@ -2532,7 +2457,6 @@ struct Walker {
                 if (ok) {
                     start_sample<!TAPE>(L, tile, iteration, area, p, spec);
                     n_ops = 0;
-                    touched |= TOUCH_NEW | TOUCH_BRIGHT | TOUCH_REFL;
                     if (COUNT) cnt.samples++;
                     if (L.bounces == 0) {
                         stage = ST_EXPOSE;
@@ -2549,7 +2473,6 @@ struct Walker {
     // SHADE: the hit/miss handling of tracer::trace (tracer.rs:222-341) up to the start of next-event estimation
     DEV void shade(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt) {
         if (stage != ST_SHADE) return;
-        touched |= TOUCH_SHADE | TOUCH_BRIGHT | TOUCH_REFL;
         const uint32_t n_add = L.spectrum_samples - 1;
         const f3 ray_o = t.o, ray_d = t.d;
         if (t.shape == PYR_HIT_NONE) {
@@ -2721,7 +2644,6 @@ struct Walker {
                     target_normal = ls_normal;
                 }
                 const float l_probability = ls_scale * material_probability;
-                touched |= TOUCH_BRIGHT;
                 if constexpr (TAPE) {
                     tape_push(L, TAPE_ADD, l_color, l_probability, l_dispersed);
                 } else if constexpr (INTERP) {
@@ -2755,7 +2677,6 @@ struct Walker {
             ls_normal = ls.normal;
             ls_tx = ls.tx, ls_ty = ls.ty;
             ls_pending = true;
-            touched |= TOUCH_LIGHT;
             // a shadow ray decided by a plane alone comes straight back to this phase
             stage = trav_begin<COUNT>(S, t, b_position, ls.direction, true, limit, cnt) ? ST_NEE : ST_TRAV;
             break;
@@ -2844,7 +2765,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
             // division instead of three; the look-ups themselves are straight-line (the clamped ends are selects).
             const uint32_t* slot_program = prepared_lds + 8 * L.tape_programs_lds;
             uint32_t grid_min = 0, grid_max = 0, grid_count = 0; // the grid i0 / mix / below / above belong to (count 0: none yet)
-            uint32_t i0 = 0;
+            uint32_t i0 = 0, i1 = 0;
             float mix = 0.0f;
             bool below = false, above = false;
             for (uint32_t slot = 0; slot < n_spectral; ++slot) {
@@ -2865,9 +2786,10 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                         const float float_index = normalized * ((float)count - 1.0f);
                         const float min_float_index = truncf(float_index);
                         i0 = (below | above) ? 0u : (uint32_t)min_float_index;
+                        i1 = (below | above) ? 0u : i0 + 1u; // a clamped wavelength reads nothing past a one-point spectrum
                         mix = float_index - min_float_index;
                     }
-                    const float inside = data[i0] * (1.0f - mix) + data[i0 + 1] * mix;
+                    const float inside = data[i0] * (1.0f - mix) + data[i1] * mix;
                     v = below ? data[0] : (above ? data[count - 1] : inside);
                 } else {
                     PyrSpectrum sp;
@@ -3121,7 +3043,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             PHASE_PRIO(PYR_PRIO_T);
             w.t.inv = box_reciprocal(w.t.d); // 1 / direction for the box tests, live in this phase only
             trav_ray_signs(w.t);
-            if (!LDS_SCENE && PYR_LEAN_STEP && !PYR_POSTPONE_LEAF && view.wide && view.pairs != nullptr) {
+            if (!LDS_SCENE && view.wide && view.pairs != nullptr) {
                 for (int step = 0; step < trav_steps; ++step) {
                     PROF_LANES(3, w.stage == ST_TRAV);
                     if (trav_step_lean<COUNT>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
@@ -3129,251 +3051,13 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             } else {
                 for (int step = 0; step < trav_steps; ++step) {
                     PROF_LANES(3, w.stage == ST_TRAV);
-                    if (trav_step_voted<COUNT, !LDS_SCENE, PYR_POSTPONE_LEAF != 0>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+                    if (trav_step_voted<COUNT, !LDS_SCENE>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
                 }
             }
             PROF_END(3);
         }
     }
     PROF_FLUSH();
-    flush_counters<COUNT>(cnt, L.counters);
-}
-
-// ------------------------------------------------------------------------------------------------ split scheduler
-// render_kernel_split: the stage-scheduled integrator with the waves of a workgroup in two roles. In render_kernel_sm every
-// wave does everything, and every phase finds a fraction of the wave's lanes: on C3 the traversal steps run with 37 of 64
-// lanes holding a ray (the others wait for a shading or light-sampling phase), SHADE and NEE with ~20. Here the first
-// PYR_SPLIT_LOGIC_WAVES waves of a workgroup own the paths (Walker state in registers; they run EXPOSE / SHADE / NEE and never
-// walk the tree) and the other waves only traverse: a logic lane posts its ray in a slot of its own in LDS and waits
-// (ST_WAIT); a traversal wave claims posted rays for its idle lanes (as intersect_kernel takes rays from a batch), steps them
-// with trav_step_lean and writes the hit back. The traversal waves are full whenever rays are waiting, and a logic wave
-// that waits issues nothing, so it can afford to wait until a phase has more lanes (sm_phase_lanes is the quorum while
-// rays are out; after PYR_SPLIT_PATIENCE empty polls the most wanted phase runs with what it has).
-//   Slots: one per logic lane, structure of arrays in the columns of the traversal-stack rows that belong to the logic lanes
-// (they walk no tree): row 0 the state word (EMPTY -> REQUESTED by the owner -> TAKEN by the traversal lane that won the
-// compare-and-swap -> DONE -> read back by the owner), rows 1-10 the ray (origin, direction, limit, the closest hit and shape
-// the planes left, shadow flag), overwritten by the result (closest, shape, u, v, blocked). Data is written before the
-// state word and read after it (LDS is in order per wave; workgroup-scope release / acquire fences keep the compiler honest).
-//   Every path performs the operations of render_kernel_sm in the same order (the Walker phases are shared), so the films
-// are identical. No wave waits for ever: both roles count their empty polls and give up with the launch's error word set.
-#ifndef PYR_SPLIT_LOGIC_WAVES
-#define PYR_SPLIT_LOGIC_WAVES 2
-#endif
-#ifndef PYR_SPLIT_PATIENCE
-#define PYR_SPLIT_PATIENCE 6
-#endif
-#ifndef PYR_SPLIT_SLEEP
-#define PYR_SPLIT_SLEEP 8
-#endif
-#ifndef PYR_SPLIT_REFILL
-#define PYR_SPLIT_REFILL 16
-#endif
-constexpr uint32_t kSplitLogicWaves = PYR_SPLIT_LOGIC_WAVES, kSplitLogicLanes = 64u * kSplitLogicWaves;
-constexpr uint32_t kSplitRows = 11; // LDS rows a slot needs (the kernel wants stack_lds >= this)
-constexpr uint32_t SLOT_EMPTY = 0u, SLOT_REQUESTED = 1u, SLOT_TAKEN = 2u, SLOT_DONE = 3u;
-constexpr uint32_t kSplitSpinLimit = 1u << 22;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-DEV uint32_t slot_load(lds_u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-DEV void slot_store(lds_u32* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-template <bool COUNT, bool LDS_TABLES>
-__global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_split(DevScene S0, RenderLaunch L) {
-    extern __shared__ float lds[];
-    const uint32_t SS = L.spectrum_samples;
-    Spectral spec{lds + threadIdx.x, SS};
-    const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots;
-    int* stack_rows = reinterpret_cast<int*>(lds + spectral_rows * BLOCK);
-    TravStack stack;
-    int deep_levels[kMaxStackDepth];
-    stack.deep = deep_levels;
-    stack.lds = (lds_int*)(stack_rows + threadIdx.x);
-    stack.lds_entries = (int)L.stack_lds;
-    Counters cnt{};
-    const uint32_t lds_base_floats = (spectral_rows + L.stack_lds) * BLOCK;
-    const SceneView view = stage_scene<false>(S0, lds, lds_base_floats, true);
-    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
-    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_TABLES ? S0.lds_table_floats : 0));
-    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
-    // slot field f of logic lane i: row f, column i of the stack rows; the count of finished logic waves: a word no lane owns
-    lds_u32* slots = (lds_u32*)reinterpret_cast<uint32_t*>(stack_rows);
-    lds_u32* logic_done = (lds_u32*)reinterpret_cast<uint32_t*>(lds + (SS + 1) * BLOCK + kSplitLogicLanes);
-    if (threadIdx.x < kSplitLogicLanes) slots[threadIdx.x] = SLOT_EMPTY;
-    if (threadIdx.x == 0) *logic_done = 0u;
-    __syncthreads();
-
-    if (wave < kSplitLogicWaves) {
-        // ------------------------------------------------------------------ logic waves: the paths
-        const uint32_t me = threadIdx.x;
-        const uint32_t total_logic_waves = gridDim.x * kSplitLogicWaves;
-        const int quorum = (int)L.sm_phase_lanes, expose_quorum = (int)L.sm_expose_lanes;
-        const float* wave_wl = lds + (threadIdx.x & ~63u);
-        float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
-        spectral_values[kTapeOneSlot * BLOCK] = 1.0f; // eager records of constant programs and BRDF factors (tape_push)
-        Walker<COUNT, false, true> w;
-        w.chunk = L.chunk_begin + blockIdx.x * kSplitLogicWaves + wave;
-        w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
-        w.tape_column = blockIdx.x * BLOCK + threadIdx.x;
-        uint32_t empty_polls = 0;
-        PROF_DECL;
-        const unsigned long long prof_start = PROF_NOW();
-        unsigned long long prof_idle = 0;
-        for (;;) {
-            if (w.stage == ST_WAIT && slot_load(slots + me) == SLOT_DONE) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                w.t.closest = __uint_as_float(slots[1 * BLOCK + me]);
-                w.t.shape = slots[2 * BLOCK + me];
-                w.t.u = __uint_as_float(slots[3 * BLOCK + me]);
-                w.t.v = __uint_as_float(slots[4 * BLOCK + me]);
-                w.t.blocked = slots[5 * BLOCK + me] != 0u;
-                w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
-            }
-            int nS = __builtin_popcountll(ballot64(w.stage == ST_SHADE));
-            int nN = __builtin_popcountll(ballot64(w.stage == ST_NEE));
-            int nE = __builtin_popcountll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
-            const int nW = __builtin_popcountll(ballot64(w.stage == ST_WAIT));
-            if (nS + nN + nE + nW == 0) break; // every lane is DONE
-            // with rays out it pays to wait for a fuller phase (waiting costs no issue slots) -- but not for ever
-            const bool patient = nW > 0 && empty_polls < (uint32_t)PYR_SPLIT_PATIENCE;
-            bool ran = false;
-            if (nE > 0 && (nE >= expose_quorum || (!patient && nE == max(max(nS, nN), nE)))) {
-                PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
-                replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
-                w.expose_and_restart(S, L, spec, cnt, lane, total_logic_waves);
-                PROF_END(0);
-                ran = true;
-                nS = __builtin_popcountll(ballot64(w.stage == ST_SHADE));
-                nE = 0;
-            }
-            if (nS > 0 && (nS >= quorum || (!patient && nS == max(max(nS, nN), nE)))) {
-                PROF_BEGIN(1, w.stage == ST_SHADE);
-                w.shade(S, L, spec, cnt);
-                PROF_END(1);
-                ran = true;
-                nN = __builtin_popcountll(ballot64(w.stage == ST_NEE));
-                nE = __builtin_popcountll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
-                nS = 0;
-            }
-            if (nN > 0 && (nN >= quorum || (!patient && nN == max(max(nS, nN), nE)))) {
-                PROF_BEGIN(2, w.stage == ST_NEE);
-                w.next_event(S, L, spec, cnt);
-                PROF_END(2);
-                ran = true;
-            }
-            if (w.stage == ST_TRAV) { // a new ray: post it
-                slots[1 * BLOCK + me] = __float_as_uint(w.t.o.x), slots[2 * BLOCK + me] = __float_as_uint(w.t.o.y), slots[3 * BLOCK + me] = __float_as_uint(w.t.o.z);
-                slots[4 * BLOCK + me] = __float_as_uint(w.t.d.x), slots[5 * BLOCK + me] = __float_as_uint(w.t.d.y), slots[6 * BLOCK + me] = __float_as_uint(w.t.d.z);
-                slots[7 * BLOCK + me] = __float_as_uint(w.t.limit);
-                slots[8 * BLOCK + me] = __float_as_uint(w.t.closest);
-                slots[9 * BLOCK + me] = w.t.shape;
-                slots[10 * BLOCK + me] = w.t.shadow ? 1u : 0u;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                slot_store(slots + me, SLOT_REQUESTED);
-                w.stage = ST_WAIT;
-            }
-            if (ran) {
-                empty_polls = 0;
-            } else {
-                const unsigned long long prof_t = PROF_NOW();
-                __builtin_amdgcn_s_sleep(PYR_SPLIT_SLEEP);
-                prof_idle += PROF_NOW() - prof_t;
-                if (++empty_polls > kSplitSpinLimit) { // the traversal waves are gone: fail loudly, do not hang the GPU
-                    *L.tape_overflow = 2u;
-                    break;
-                }
-            }
-        }
-        PROF_EXTRA(12, prof_idle);
-        PROF_EXTRA(14, PROF_NOW() - prof_start);
-        PROF_FLUSH();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(logic_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        // ------------------------------------------------------------------ traversal waves: the rays
-        const int trav_steps = (int)L.sm_trav_steps;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        Trav t{};
-        t.node = 0, t.sp = 0;
-        bool busy = false;
-        uint32_t slot = 0, empty_polls = 0;
-        PROF_DECL;
-        const unsigned long long prof_start = PROF_NOW();
-        unsigned long long prof_idle = 0;
-        for (;;) {
-            const unsigned long long busy_mask = ballot64(busy);
-            int n_idle = 64 - __builtin_popcountll(busy_mask);
-            if (n_idle >= PYR_SPLIT_REFILL) {
-                // claim posted rays, at most one per idle lane: 64 slots at a time, the two traversal waves from opposite ends
-                uint32_t claimed = 0;
-                for (uint32_t part = 0; part < kSplitLogicWaves; ++part) {
-                    const uint32_t candidate = ((part + wave) % kSplitLogicWaves) * 64u + lane;
-                    const bool posted = slot_load(slots + candidate) == SLOT_REQUESTED;
-                    const unsigned long long posted_mask = ballot64(posted);
-                    bool mine = false;
-                    if (posted && __builtin_popcountll(posted_mask & below) < n_idle) {
-                        uint32_t expected = SLOT_REQUESTED; // the other traversal wave may have been faster
-                        mine = __hip_atomic_compare_exchange_strong(slots + candidate, &expected, SLOT_TAKEN, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    const unsigned long long mine_mask = ballot64(mine);
-                    if (mine) wave_list[claimed + __builtin_popcountll(mine_mask & below)] = candidate;
-                    const int got = __builtin_popcountll(mine_mask);
-                    claimed += (uint32_t)got;
-                    n_idle -= got;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t rank = (uint32_t)__builtin_popcountll(~busy_mask & below);
-                if (!busy && rank < claimed) {
-                    slot = wave_list[rank];
-                    t.o = mk(__uint_as_float(slots[1 * BLOCK + slot]), __uint_as_float(slots[2 * BLOCK + slot]), __uint_as_float(slots[3 * BLOCK + slot]));
-                    t.d = mk(__uint_as_float(slots[4 * BLOCK + slot]), __uint_as_float(slots[5 * BLOCK + slot]), __uint_as_float(slots[6 * BLOCK + slot]));
-                    t.limit = __uint_as_float(slots[7 * BLOCK + slot]);
-                    t.closest = __uint_as_float(slots[8 * BLOCK + slot]);
-                    t.shape = slots[9 * BLOCK + slot];
-                    t.shadow = slots[10 * BLOCK + slot] != 0u;
-                    t.u = t.v = 0.0f;
-                    trav_restart(t);
-                    t.inv = box_reciprocal(t.d);
-                    trav_ray_signs(t);
-                    busy = true;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (ballot64(busy) == 0ull) {
-                if (slot_load(logic_done) == kSplitLogicWaves) break; // every path of this workgroup is finished
-                const unsigned long long prof_t = PROF_NOW();
-                __builtin_amdgcn_s_sleep(PYR_SPLIT_SLEEP);
-                prof_idle += PROF_NOW() - prof_t;
-                if (++empty_polls > kSplitSpinLimit) {
-                    *L.tape_overflow = 2u;
-                    break;
-                }
-                continue;
-            }
-            empty_polls = 0;
-#ifdef PYR_PHASE_PROFILE
-            const unsigned long long prof_t0_3 = clock64();
-#endif
-            for (int step = 0; step < trav_steps; ++step) {
-                PROF_LANES(3, busy);
-                if (trav_step_lean<COUNT>(view, t, stack, cnt, busy)) {
-                    slots[1 * BLOCK + slot] = __float_as_uint(t.closest);
-                    slots[2 * BLOCK + slot] = t.shape;
-                    slots[3 * BLOCK + slot] = __float_as_uint(t.u);
-                    slots[4 * BLOCK + slot] = __float_as_uint(t.v);
-                    slots[5 * BLOCK + slot] = t.blocked ? 1u : 0u;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    slot_store(slots + slot, SLOT_DONE);
-                    busy = false;
-                }
-            }
-            PROF_END(3);
-        }
-        PROF_EXTRA(13, prof_idle);
-        PROF_EXTRA(15, PROF_NOW() - prof_start);
-        PROF_FLUSH();
-    }
     flush_counters<COUNT>(cnt, L.counters);
 }
 
@@ -3488,408 +3172,6 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(D
         }
     }
     flush_counters<COUNT>(cnt, L.counters);
-}
-
-// =================================================================================================
-// Wavefront integrator (wf_logic_kernel + wf_trav_kernel) -- big scenes
-//
-// On a scene that lives in HBM the stage-scheduled kernel is latency bound: its 128 registers and ~40 KB of LDS per
-// workgroup allow 4 waves per SIMD, and measured speed follows that occupancy (2 -> 3 -> 4 workgroups per CU: 103 -> 135
-// -> 160 Msamples/s on C3) while 71 % of its wave cycles are tree walking at half lane occupancy. The wavefront form
-// splits the state machine at the ray: path state lives in a pool in HBM (288 GB: 4 M paths are 1.3 GB),
-//     wf_logic_kernel   one thread per pool slot: runs SHADE / NEE / EXPOSE / NEW (the Walker phases above) until the
-//                       path needs a ray, stores the state and the ray
-//     wf_trav_kernel    persistent waves with dynamic fetch over the pool (the intersect kernel's loop: 63 registers,
-//                       8 waves per SIMD, short LDS stack), writes the hit back
-// and the host alternates the two until no path has a ray left. Slot s owns the sample sequence of "wave" s / 64, lane
-// s % 64 of the chunk schedule, exactly as a lane of the stage-scheduled kernel does, and runs the same Walker code in the
-// same order, so films are identical to the other schedulers'.
-// =================================================================================================
-constexpr uint32_t WF_STAGE_MASK = 0xffu, WF_BLOCKED = 0x100u, WF_SHADOW = 0x200u;
-
-DEV float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
-DEV f3 xyz(float4 v) { return mk(v.x, v.y, v.z); }
-
-// State groups (float4 each, [group][slot]):
-//   0 chunk | bounce, events, flags | nee_lamp | nee_i        6 closest, shape, u, v (planes' result in, hit out)
-//   1 rng                                                     7 b_position     8 b_normal     9 b_out     10 b_nff
-//   2 pixel, -, wl, bright                                    11 ls_normal (+ ls_ty; ls_tx rides in 10.w)
-//   3 refl, nee_probability, ls_scale, ls_color
-//   4 ray origin, limit        5 ray direction, ls_material
-// A visit loads what its entry stage reads (a path coming back from an extension ray does not need the light-sample
-// context, one coming back from a shadow ray does not need the hit) and stores what it changed (Walker::touched).
-template <bool COUNT, bool INTERP>
-DEV void wf_load(const WfPool& P, uint32_t slot, uint32_t word, bool planes, Walker<COUNT, INTERP>& w, Spectral& spec, uint32_t n_comp) {
-    w.stage = word & WF_STAGE_MASK;
-    w.t.blocked = (word & WF_BLOCKED) != 0;
-    w.t.shadow = (word & WF_SHADOW) != 0;
-    const float4* g = reinterpret_cast<const float4*>(P.groups) + slot;
-    const size_t n = P.n;
-    const float4 g0 = g[0 * n];
-    w.chunk = __float_as_uint(g0.x);
-    if (w.stage == ST_NEW) return;
-    const float4 g1 = g[1 * n], g2 = g[2 * n], g3 = g[3 * n], g5 = g[5 * n];
-    const uint32_t packed = __float_as_uint(g0.y);
-    w.p.bounce = packed & 0xffffu;
-    w.p.events = (packed >> 16) & 0xffu;
-    w.p.use_additional = (packed >> 24) & 1u;
-    w.p.sample_light = (packed >> 25) & 1u;
-    w.b_has_brdf = (packed >> 26) & 1u;
-    w.ls_pending = (packed >> 27) & 1u;
-    w.ls_physical = (packed >> 28) & 1u;
-    w.nee_lamp = __float_as_uint(g0.z);
-    w.nee_i = __float_as_uint(g0.w);
-    w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
-    w.p.pixel = __float_as_uint(g2.x), w.p.wl = g2.z, w.p.bright = g2.w;
-    w.p.refl = g3.x, w.ls_scale = g3.z, w.ls_color = __float_as_uint(g3.w);
-    w.t.d = xyz(g5), w.ls_material = __float_as_uint(g5.w);
-    if (w.stage == ST_NEE) {
-        const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n], g10 = g[10 * n], g11 = g[11 * n];
-        w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9), w.ls_normal = xyz(g11);
-        w.b_flip = __float_as_uint(g9.w) != 0u;
-        w.ls_tx = g10.w, w.ls_ty = g11.w;
-        w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event)
-    } else {
-        const float4 g4 = g[4 * n];
-        w.t.o = xyz(g4), w.t.limit = g4.w;
-        if (planes || w.stage == ST_SHADE) {
-            const float4 g6 = g[6 * n];
-            w.t.closest = g6.x, w.t.shape = __float_as_uint(g6.y), w.t.u = g6.z, w.t.v = g6.w;
-        }
-    }
-    w.p.o = w.t.o, w.p.d = w.t.d;
-    const float* c = P.companions + slot;
-    for (uint32_t k = 0; k < n_comp; ++k) {
-        spec.wl(k) = c[(size_t)(0 * n_comp + k) * n];
-        spec.bright(k) = c[(size_t)(1 * n_comp + k) * n];
-        spec.refl(k) = c[(size_t)(2 * n_comp + k) * n];
-    }
-}
-
-template <bool COUNT, bool INTERP>
-DEV void wf_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUNT, INTERP>& w, Spectral& spec, uint32_t n_comp) {
-    float4* g = reinterpret_cast<float4*>(P.groups) + slot;
-    const size_t n = P.n;
-    const uint32_t packed = (w.p.bounce & 0xffffu) | ((w.p.events & 0xffu) << 16) | ((uint32_t)w.p.use_additional << 24) |
-                            ((uint32_t)w.p.sample_light << 25) | ((uint32_t)w.b_has_brdf << 26) | ((uint32_t)w.ls_pending << 27) |
-                            ((uint32_t)w.ls_physical << 28);
-    g[0 * n] = make_float4(__uint_as_float(w.chunk), __uint_as_float(packed), __uint_as_float(w.nee_lamp), __uint_as_float(w.nee_i));
-    P.stage[slot] = w.stage | (w.t.shadow ? WF_SHADOW : 0u);
-    if (w.stage == ST_DONE) return;
-    g[1 * n] = make_float4(__uint_as_float(w.p.rng.x), __uint_as_float(w.p.rng.y), __uint_as_float(w.p.rng.z), __uint_as_float(w.p.rng.w));
-    g[2 * n] = make_float4(__uint_as_float(w.p.pixel), 0.0f, w.p.wl, w.p.bright);
-    g[3 * n] = make_float4(w.p.refl, 0.0f, w.ls_scale, __uint_as_float(w.ls_color));
-    g[4 * n] = mk4(w.t.o, w.t.limit);
-    g[5 * n] = mk4(w.t.d, __uint_as_float(w.ls_material));
-    if (planes) g[6 * n] = make_float4(w.t.closest, __uint_as_float(w.t.shape), w.t.u, w.t.v);
-    if (w.touched & TOUCH_SHADE) {
-        g[7 * n] = mk4(w.b_position, 0.0f);
-        g[8 * n] = mk4(w.b_normal, 0.0f);
-        g[9 * n] = mk4(w.b_out, __uint_as_float(w.b_flip ? 1u : 0u));
-        g[10 * n] = mk4(w.b_nff(), 0.0f);
-    }
-    if (w.touched & TOUCH_LIGHT) g[11 * n] = mk4(w.ls_normal, w.ls_ty);
-    if (INTERP && (w.touched & TOUCH_LIGHT)) g[10 * n] = mk4(w.b_nff(), w.ls_tx); // the light sample's texture coordinates ride in the spare lanes
-    float* c = P.companions + slot;
-    if (w.touched & TOUCH_NEW)
-        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(0 * n_comp + k) * n] = spec.wl(k);
-    if (w.touched & TOUCH_BRIGHT)
-        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(1 * n_comp + k) * n] = spec.bright(k);
-    if (w.touched & TOUCH_REFL)
-        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)(2 * n_comp + k) * n] = spec.refl(k);
-}
-
-__global__ __launch_bounds__(BLOCK) void wf_init_kernel(WfPool P, uint32_t chunk_begin) {
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
-    if (slot >= P.n) return;
-    P.stage[slot] = ST_NEW;
-    reinterpret_cast<float4*>(P.groups)[slot] = make_float4(__uint_as_float(chunk_begin + slot / 64u), 0.0f, 0.0f, 0.0f);
-}
-
-template <bool COUNT, bool INTERP>
-__global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : 4) void wf_logic_kernel(DevScene S0, RenderLaunch L, WfPool P) {
-    extern __shared__ float lds[];
-    const uint32_t SS = L.spectrum_samples;
-    Spectral spec{lds + threadIdx.x, SS};
-    Counters cnt{};
-    const DevScene S = stage_tables<-1>(S0, lds, 3 * SS * BLOCK);
-    if (blockIdx.x == 0 && threadIdx.x < kFeedSegments) P.next[threadIdx.x * kFeedCursorStride] = 0; // the traversal kernel that follows starts afresh
-    // The workgroup owns BLOCK consecutive slots. Its threads take them sorted by entry stage (SHADE, NEE, NEW, done) so that
-    // a wave runs one phase body instead of every body at partial occupancy; the slots stay within one 4 KB window per state
-    // group, so the permuted loads and stores touch the same cache lines as unpermuted ones.
-    __shared__ uint32_t wave_counts[BLOCK / 64][4];
-    __shared__ uint16_t sorted_slot[BLOCK];
-    const uint32_t first_slot = blockIdx.x * BLOCK;
-    uint32_t my_word = ST_DONE;
-    if (first_slot + threadIdx.x < P.n) my_word = P.stage[first_slot + threadIdx.x];
-    const uint32_t my_stage = my_word & WF_STAGE_MASK;
-    const uint32_t key = my_stage == ST_SHADE ? 0u : (my_stage == ST_NEE ? 1u : (my_stage == ST_DONE ? 3u : 2u));
-    const uint32_t lane_id = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
-    uint32_t rank_in_wave = 0;
-    for (uint32_t k = 0; k < 4; ++k) {
-        const unsigned long long m = ballot64(key == k);
-        if (key == k) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane_id) - 1ull));
-        if (lane_id == 0) wave_counts[wave_id][k] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    uint32_t position = rank_in_wave;
-    for (uint32_t k = 0; k < 4; ++k)
-        for (uint32_t v = 0; v < BLOCK / 64; ++v)
-            if (k < key || (k == key && v < wave_id)) position += wave_counts[v][k];
-    sorted_slot[position] = (uint16_t)threadIdx.x;
-    __syncthreads();
-    const uint32_t slot = first_slot + sorted_slot[threadIdx.x];
-    const bool live = slot < P.n;
-    const uint32_t n_comp = SS - 1;
-    const uint32_t total_waves = P.n / 64u;
-    Walker<COUNT, INTERP> w;
-    w.stage = ST_DONE;
-    const bool planes = S.num_planes != 0;
-    if (live) {
-        const uint32_t word = P.stage[slot];
-        if ((word & WF_STAGE_MASK) != ST_DONE) wf_load(P, slot, word, planes, w, spec, n_comp);
-    }
-    const bool had_work = w.stage != ST_DONE;
-    for (;;) {
-        const bool any_shade = ballot64(w.stage == ST_SHADE) != 0;
-        const bool any_nee = ballot64(w.stage == ST_NEE) != 0;
-        const bool any_end = ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0;
-        if (!(any_shade || any_nee || any_end)) break; // every lane holds a ray to trace, or is done
-        if (any_shade) w.shade(S, L, spec, cnt);
-        if (ballot64(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
-        if constexpr (INTERP) w.contribute_pending(S, L, spec); // before a path that has just ended is exposed
-        if (ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW) != 0) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
-    }
-    if (had_work) wf_store(P, slot, planes, w, spec, n_comp);
-    if (ballot64(w.stage == ST_TRAV) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u;
-    flush_counters<COUNT>(cnt, L.counters);
-}
-
-// ---- the wavefront logic kernel with the spectral tape (scenes without interpreter programs: every BASELINE config) ----------
-// Same split as above, but `contribute` does not run in the visits: they append to the slot's column of the tape (Walker
-// TAPE) and the visit in which a path ends replays it, wave-wide, exactly as the stage-scheduled kernel does. The state a
-// visit moves shrinks accordingly -- no brightness / reflectance, the S - 1 companion wavelengths are written when a sample
-// starts and read again only when it is exposed:
-//   0 chunk | bounce:12 n_ops:12 events:2 flags:6 | nee_lamp:16 nee_i:16 | pixel        4 ray origin, limit     5 ray direction
-//   1 rng                                                                              6 closest, shape, u, v
-//   2 wl (hero), ls_scale, ls_color, ls_material                                        7 b_position   8 b_normal   9 b_out
-// nee_probability is a function of the launch alone and b_nff is +-b_normal (one flag bit). A visit that comes back from an
-// extension ray reads 0 1 2 4 5 6, one that comes back from a shadow ray 0 1 2 7 8 9; both write 0 1 (2) 4 5, and 7 8 9 when
-// a next-event estimation starts: ~190 B per visit against ~345 B before, and a third of the phase code.
-constexpr uint32_t WFT_FLAG_ADDITIONAL = 1u << 26, WFT_FLAG_SAMPLE_LIGHT = 1u << 27, WFT_FLAG_HAS_BRDF = 1u << 28, WFT_FLAG_LS_PENDING = 1u << 29,
-                   WFT_FLAG_LS_PHYSICAL = 1u << 30, WFT_FLAG_NFF_FLIPPED = 1u << 31;
-
-template <bool COUNT>
-DEV void wft_load(const DevScene& S, const RenderLaunch& L, const WfPool& P, uint32_t slot, uint32_t word, Walker<COUNT, false, true>& w) {
-    w.stage = word & WF_STAGE_MASK;
-    w.t.blocked = (word & WF_BLOCKED) != 0;
-    w.t.shadow = (word & WF_SHADOW) != 0;
-    const float4* g = reinterpret_cast<const float4*>(P.groups) + slot;
-    const size_t n = P.n;
-    const float4 g0 = g[0 * n];
-    w.chunk = __float_as_uint(g0.x);
-    if (w.stage == ST_NEW) return;
-    const float4 g2 = g[2 * n];
-    const uint32_t packed = __float_as_uint(g0.y), nee = __float_as_uint(g0.z);
-    w.p.pixel = __float_as_uint(g0.w);
-    w.p.wl = g2.x;
-    w.n_ops = (packed >> 12) & 0xfffu;
-    w.p.use_additional = (packed & WFT_FLAG_ADDITIONAL) != 0;
-    if (w.stage == ST_EXPOSE) return; // a path that ended in the last visit: the replay needs its tape, pixel, wavelengths and this flag
-    const float4 g1 = g[1 * n];
-    w.p.bounce = packed & 0xfffu;
-    w.p.events = (packed >> 24) & 3u;
-    w.p.sample_light = (packed & WFT_FLAG_SAMPLE_LIGHT) != 0;
-    w.b_has_brdf = (packed & WFT_FLAG_HAS_BRDF) != 0;
-    w.ls_pending = (packed & WFT_FLAG_LS_PENDING) != 0;
-    w.ls_physical = (packed & WFT_FLAG_LS_PHYSICAL) != 0;
-    w.nee_lamp = nee & 0xffffu;
-    w.nee_i = nee >> 16;
-    w.p.rng = Rng{__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};
-    w.ls_scale = g2.y, w.ls_color = __float_as_uint(g2.z), w.ls_material = __float_as_uint(g2.w);
-    if (w.stage == ST_NEE) {
-        const float4 g7 = g[7 * n], g8 = g[8 * n], g9 = g[9 * n];
-        w.b_position = xyz(g7), w.b_normal = xyz(g8), w.b_out = xyz(g9);
-        w.b_flip = (packed & WFT_FLAG_NFF_FLIPPED) != 0;
-        w.t.o = w.b_position; // a shadow ray starts at the bounce (next_event); its direction is not read again
-    } else {
-        const float4 g4 = g[4 * n], g5 = g[5 * n], g6 = g[6 * n];
-        w.t.o = xyz(g4), w.t.limit = g4.w, w.t.d = xyz(g5);
-        w.t.closest = g6.x, w.t.shape = __float_as_uint(g6.y), w.t.u = g6.z, w.t.v = g6.w;
-    }
-    w.p.o = w.t.o, w.p.d = w.t.d;
-}
-
-template <bool COUNT>
-DEV void wft_store(const WfPool& P, uint32_t slot, bool planes, const Walker<COUNT, false, true>& w, Spectral& spec, uint32_t n_comp) {
-    float4* g = reinterpret_cast<float4*>(P.groups) + slot;
-    const size_t n = P.n;
-    const bool flipped = w.b_flip;
-    const uint32_t packed = (w.p.bounce & 0xfffu) | ((w.n_ops & 0xfffu) << 12) | ((w.p.events & 3u) << 24) | (w.p.use_additional ? WFT_FLAG_ADDITIONAL : 0u) |
-                            (w.p.sample_light ? WFT_FLAG_SAMPLE_LIGHT : 0u) | (w.b_has_brdf ? WFT_FLAG_HAS_BRDF : 0u) | (w.ls_pending ? WFT_FLAG_LS_PENDING : 0u) |
-                            (w.ls_physical ? WFT_FLAG_LS_PHYSICAL : 0u) | (flipped ? WFT_FLAG_NFF_FLIPPED : 0u);
-    g[0 * n] = make_float4(__uint_as_float(w.chunk), __uint_as_float(packed), __uint_as_float((w.nee_lamp & 0xffffu) | (w.nee_i << 16)), __uint_as_float(w.p.pixel));
-    P.stage[slot] = w.stage | (w.t.shadow ? WF_SHADOW : 0u);
-    if (w.stage == ST_DONE || w.stage == ST_EXPOSE) return; // EXPOSE: parked for the next visit, which replays its tape (group 2 holds its wavelength since the sample started)
-    g[1 * n] = make_float4(__uint_as_float(w.p.rng.x), __uint_as_float(w.p.rng.y), __uint_as_float(w.p.rng.z), __uint_as_float(w.p.rng.w));
-    if (w.touched & (TOUCH_NEW | TOUCH_LIGHT)) g[2 * n] = make_float4(w.p.wl, w.ls_scale, __uint_as_float(w.ls_color), __uint_as_float(w.ls_material));
-    g[4 * n] = mk4(w.t.o, w.t.limit);
-    g[5 * n] = mk4(w.t.d, 0.0f);
-    if (planes) g[6 * n] = make_float4(w.t.closest, __uint_as_float(w.t.shape), w.t.u, w.t.v);
-    if ((w.touched & TOUCH_SHADE) && w.ls_pending) { // a next-event estimation started in this visit: its context outlives the visit
-        g[7 * n] = mk4(w.b_position, 0.0f);
-        g[8 * n] = mk4(w.b_normal, 0.0f);
-        g[9 * n] = mk4(w.b_out, 0.0f);
-    }
-    if (w.touched & TOUCH_NEW) {
-        float* c = P.companions + slot;
-        for (uint32_t k = 0; k < n_comp; ++k) c[(size_t)k * n] = spec.wl(k);
-    }
-}
-
-template <bool COUNT, bool LDS_TABLES>
-__global__ __launch_bounds__(BLOCK, 4) void wf_logic_tape_kernel(DevScene S0, RenderLaunch L, WfPool P) {
-    extern __shared__ float lds[];
-    const uint32_t SS = L.spectrum_samples;
-    Spectral spec{lds + threadIdx.x, SS};
-    Counters cnt{};
-    const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots; // S wavelengths, the per-wave lane lists, the eager value rows (replay_tapes)
-    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, spectral_rows * BLOCK);
-    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + spectral_rows * BLOCK + (LDS_TABLES ? S0.lds_table_floats : 0));
-    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
-    const float* wave_wl = lds + (threadIdx.x & ~63u);
-    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
-    float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
-    spectral_values[kTapeOneSlot * BLOCK] = 1.0f; // eager records of constant programs and BRDF factors (tape_push)
-    if (blockIdx.x == 0 && threadIdx.x < kFeedSegments) P.next[threadIdx.x * kFeedCursorStride] = 0; // the traversal kernel that follows starts afresh
-    // threads take the workgroup's slots sorted by entry stage (see wf_logic_kernel)
-    __shared__ uint32_t wave_counts[BLOCK / 64][4];
-    __shared__ uint16_t sorted_slot[BLOCK];
-    const uint32_t first_slot = blockIdx.x * BLOCK;
-    uint32_t my_word = ST_DONE;
-    if (first_slot + threadIdx.x < P.n) my_word = P.stage[first_slot + threadIdx.x];
-    const uint32_t my_stage = my_word & WF_STAGE_MASK;
-    const uint32_t key = my_stage == ST_SHADE ? 0u : (my_stage == ST_NEE ? 1u : (my_stage == ST_DONE ? 3u : 2u));
-    const uint32_t lane_id = threadIdx.x & 63u, wave_id = threadIdx.x >> 6;
-    uint32_t rank_in_wave = 0;
-    for (uint32_t k = 0; k < 4; ++k) {
-        const unsigned long long m = ballot64(key == k);
-        if (key == k) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane_id) - 1ull));
-        if (lane_id == 0) wave_counts[wave_id][k] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    uint32_t position = rank_in_wave;
-    for (uint32_t k = 0; k < 4; ++k)
-        for (uint32_t v = 0; v < BLOCK / 64; ++v)
-            if (k < key || (k == key && v < wave_id)) position += wave_counts[v][k];
-    sorted_slot[position] = (uint16_t)threadIdx.x;
-    __syncthreads();
-    const uint32_t slot = first_slot + sorted_slot[threadIdx.x];
-    const bool live = slot < P.n;
-    const uint32_t n_comp = SS - 1;
-    const uint32_t total_waves = P.n / 64u;
-    Walker<COUNT, false, true> w;
-    w.stage = ST_DONE;
-    w.tape_column = slot;
-    w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
-    const bool planes = S.num_planes != 0;
-    if (live) {
-        const uint32_t word = P.stage[slot];
-        if ((word & WF_STAGE_MASK) != ST_DONE) wft_load(S, L, P, slot, word, w);
-    }
-    const bool had_work = w.stage != ST_DONE;
-    // A path that ends in this visit is PARKED in EXPOSE and replayed by the next visit: the threads of a workgroup take their
-    // slots sorted by entry stage, so the parked paths of 256 slots then sit side by side and the replay (and the start of the
-    // next sample behind it) runs at the width of a wave -- done on the spot it ran for the three or four lanes of a wave that
-    // happen to finish in a round, every round (3.3 ms per round of 16 Mi slots against the traversal kernel's 1.9).
-    const bool ending = w.stage == ST_EXPOSE || w.stage == ST_NEW; // entered the visit at the end of a path (or before its first)
-    if (w.stage == ST_EXPOSE) { // the companions were put down in HBM when the sample started
-        const float* c = P.companions + slot;
-        for (uint32_t k = 0; k < n_comp; ++k) spec.wl(k) = c[(size_t)k * P.n];
-    }
-    if (ballot64(ending) != 0) {
-        replay_tapes<COUNT>(S, L, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
-        if (ending) w.expose_and_restart(S, L, spec, cnt, slot & 63u, total_waves);
-    }
-    for (;;) {
-        const bool any_shade = ballot64(w.stage == ST_SHADE) != 0;
-        const bool any_nee = ballot64(w.stage == ST_NEE) != 0;
-        if (!(any_shade || any_nee)) break; // every lane holds a ray to trace, is parked at its path's end, or is done
-        if (any_shade) w.shade(S, L, spec, cnt);
-        if (ballot64(w.stage == ST_NEE) != 0) w.next_event(S, L, spec, cnt);
-    }
-    if (had_work) wft_store(P, slot, planes, w, spec, n_comp);
-    if (ballot64(w.stage == ST_TRAV || w.stage == ST_EXPOSE) != 0 && (threadIdx.x & 63u) == 0) *P.work_flag = 1u; // parked paths need another round too
-    flush_counters<COUNT>(cnt, L.counters);
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void wf_trav_kernel(DevScene S, WfPool P, uint32_t reserve, uint32_t stack_lds, unsigned long long* counters) {
-    extern __shared__ int lds_stack[];
-    TravStack stack;
-    int deep_levels[kMaxStackDepth];
-    stack.deep = deep_levels;
-    stack.lds = (lds_int*)(lds_stack + threadIdx.x);
-    stack.lds_entries = (int)stack_lds;
-    Counters cnt{};
-    SceneView view = wide_or_binary_view(S);
-    const bool lean = PYR_INTERSECT_PAIRS && S.wide_nodes != nullptr && S.pair_prims != nullptr; // as intersect_kernel
-    if (lean) {
-        view.nodes = reinterpret_cast<const float4*>(S.wide_pair_nodes);
-        view.pairs = reinterpret_cast<const float4*>(S.pair_prims);
-    }
-    const uint32_t lane = threadIdx.x & 63u;
-    constexpr int kRefillLanes = 16, kSteps = 4;
-    const size_t n = P.n;
-    bool busy = false;
-    uint32_t slot = 0;
-    Trav t{};
-    WorkFeed feed;
-    feed.segment = blockIdx.x % kFeedSegments;
-    for (;;) {
-        const unsigned long long idle_mask = ballot64(!busy);
-        const int idle = __popcll(idle_mask);
-        if (!feed.drained && (idle >= kRefillLanes || idle == 64)) {
-            feed_reserve(feed, P.next, P.n, reserve, lane);
-            if (!feed.drained) {
-                const uint32_t available = feed.end - feed.next;
-                const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-                if (!busy && rank < available) {
-                    slot = feed.next + rank;
-                    const uint32_t word = P.stage[slot];
-                    if ((word & WF_STAGE_MASK) == ST_TRAV) {
-                        const float4* G = reinterpret_cast<const float4*>(P.groups);
-                        const float4 g4 = G[4 * n + slot], g5 = G[5 * n + slot];
-                        t.o = xyz(g4), t.d = xyz(g5);
-                        t.limit = g4.w;
-                        t.shadow = (word & WF_SHADOW) != 0;
-                        t.closest = PYR_INF, t.shape = PYR_HIT_NONE, t.u = t.v = 0.0f; // trav_begin's start without planes
-                        if (S.num_planes != 0) {
-                            const float4 g6 = G[6 * n + slot];
-                            t.closest = g6.x, t.shape = __float_as_uint(g6.y), t.u = g6.z, t.v = g6.w;
-                        }
-                        trav_restart(t);
-                        t.inv = box_reciprocal(t.d);
-                        trav_ray_signs(t);
-                        busy = true;
-                    }
-                }
-                feed.next += min((uint32_t)idle, available);
-            }
-        }
-        if (ballot64(busy) == 0) {
-            if (feed.drained) break;
-            continue;
-        }
-        for (int step = 0; step < kSteps; ++step) {
-            if (lean ? trav_step_lean<COUNT>(view, t, stack, cnt, busy) : trav_step_voted<COUNT>(view, t, stack, cnt, busy)) {
-                if (!t.shadow) reinterpret_cast<float4*>(P.groups)[6 * n + slot] = make_float4(t.closest, __uint_as_float(t.shape), t.u, t.v);
-                P.stage[slot] = t.shadow ? (ST_NEE | WF_SHADOW | (t.blocked ? WF_BLOCKED : 0u)) : ST_SHADE;
-                busy = false;
-            }
-        }
-    }
-    flush_counters<COUNT>(cnt, counters);
 }
 
 // ------------------------------------------------------------------------------------------------ film development
@@ -4077,7 +3359,7 @@ uint32_t tape_ops_bound(const RenderLaunch& launch) { return 2u * launch.bounces
 uint32_t tape_lanes_bound(int num_cus) { return (uint32_t)num_cus * 8u * BLOCK; } // launch_render never starts more than 8 blocks per CU
 constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for the replay (4 KB); scenes with more use the HBM records
 static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_programs <= kTapeProgramsLds ? scene.num_programs : 0u; }
-static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return (launch.scheduler == 1 || launch.scheduler == 3) && scene.needs_interpreter == 0; }
+static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return launch.scheduler == 1 && scene.needs_interpreter == 0; }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
     size_t bytes = (spectral_rows + launch.stack_lds) * BLOCK * sizeof(float);
@@ -4121,22 +3403,11 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.stack_lds = 0;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernels are built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
-    launch.stack_lds = launch.scheduler == 1 || launch.scheduler == 3
-                           ? short_stack_levels(scene, render_lds_bytes(scene, launch), launch.scheduler == 1 && scene.needs_interpreter != 0 ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
-                           : scene.stack_depth;
+    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
+                                             : scene.stack_depth;
     // a scene staged in LDS is a few dozen nodes: its whole stack is kept in LDS (the kernels built for such scenes have no
-    // scratch part), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below still applies
-    if (launch.scheduler == 1 && scene_fits_lds(scene)) launch.stack_lds = std::max(launch.stack_lds, scene.stack_depth);
-    // the split scheduler walks four-child trees with triangle pairs only, keeps its slots in the stack rows and has no
-    // interpreter form: anything else runs on the stage scheduler
-    if (launch.scheduler == 3 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene) || launch.stack_lds < kSplitRows)) {
-        if (const char* strict = std::getenv("PYRITE_SCHEDULER_STRICT")) // test switch: a forced scheduler that cannot run is an error, not a fallback
-            if (*strict == '1') {
-                g_kernel_error = "PYRITE_SCHEDULER=split cannot run this scene (needs the four-child pair tree, no interpreter programs, >= 11 LDS stack levels)";
-                return PYR_ERR_UNSUPPORTED;
-            }
-        launch.scheduler = 1;
-    }
+    // scratch part: TravStack::deep is one entry), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below applies
+    if (scene_fits_lds(scene)) launch.stack_lds = std::max(launch.stack_lds, scene.stack_depth);
     const size_t lds = render_lds_bytes(scene, launch);
     if (lds > 160 * 1024) {
         g_kernel_error = "spectrum_samples + BVH depth need more than 160 KB of LDS per workgroup";
@@ -4145,11 +3416,6 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
     RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0);
-    if (launch.scheduler == 3) {
-        static const RenderKernel split_variants[2][2] = {{render_kernel_split<false, false>, render_kernel_split<false, true>},
-                                                          {render_kernel_split<true, false>, render_kernel_split<true, true>}};
-        kernel = split_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0];
-    }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
@@ -4166,7 +3432,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     }
     blocks_per_cu = std::max(1, std::min<int>(blocks_per_cu, (int)((160 * 1024) / std::max<size_t>(lds, 1))));
     uint32_t grid = (uint32_t)num_cus * (uint32_t)blocks_per_cu;
-    const uint32_t path_waves = launch.scheduler == 3 ? kSplitLogicWaves : BLOCK / 64; // waves of a workgroup that take chunks
+    const uint32_t path_waves = BLOCK / 64; // waves of a workgroup that take chunks
     uint32_t blocks_needed = (chunks + path_waves - 1) / path_waves;
     if (grid > blocks_needed) grid = blocks_needed;
     if (uses_tape(scene, launch) && (launch.tape == nullptr || (size_t)grid * BLOCK > launch.tape_lanes || launch.tape_max_ops < tape_ops_bound(launch))) {
@@ -4213,83 +3479,6 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
     if (err != hipSuccess) {
         g_kernel_error = std::string("intersect kernel launch: ") + hipGetErrorString(err);
         return PYR_ERR_DEVICE;
-    }
-    return PYR_OK;
-}
-
-bool wavefront_uses_tape(const DevScene& scene, const RenderLaunch& launch) {
-    return scene.needs_interpreter == 0 && launch.bounces < 4096u && tape_ops_bound(launch) < 4096u && scene.num_lamps < 65536u && launch.light_samples < 65536u;
-}
-
-int launch_wavefront(const DevScene& scene, const RenderLaunch& launch_in, bool with_counters, void* stream_, int num_cus, const WfPool& pool,
-                     volatile uint32_t* host_flag) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (scene.stack_depth > kMaxStackDepth) {
-        g_kernel_error = "BVH deeper than kMaxStackDepth";
-        return PYR_ERR_UNSUPPORTED;
-    }
-    if (launch_in.chunk_end == launch_in.chunk_begin || pool.n == 0) return PYR_OK;
-    RenderLaunch launch = launch_in;
-    launch.stack_lds = short_stack_levels(scene, 0, 8);
-    const bool interp = scene.needs_interpreter != 0;
-    using LogicKernel = void (*)(DevScene, RenderLaunch, WfPool);
-    static const LogicKernel logic_variants[2][2] = {{wf_logic_kernel<false, false>, wf_logic_kernel<false, true>},
-                                                     {wf_logic_kernel<true, false>, wf_logic_kernel<true, true>}};
-    static const LogicKernel tape_variants[2][2] = {{wf_logic_tape_kernel<false, false>, wf_logic_tape_kernel<false, true>},
-                                                    {wf_logic_tape_kernel<true, false>, wf_logic_tape_kernel<true, true>}};
-    // the tape form packs bounce / record counts into 12 bits each and the lamp / light-sample numbers into 16
-    const bool tape = wavefront_uses_tape(scene, launch);
-    LogicKernel logic = tape ? tape_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0] : logic_variants[with_counters ? 1 : 0][interp ? 1 : 0];
-    auto trav = with_counters ? wf_trav_kernel<true> : wf_trav_kernel<false>;
-    size_t lds_logic = (size_t)3 * launch.spectrum_samples * BLOCK * sizeof(float) + (size_t)scene.lds_table_floats * sizeof(float);
-    if (tape) {
-        launch.tape_programs_lds = tape_programs_in_lds(scene);
-        if (launch.tape == nullptr || launch.tape_lanes < pool.n || launch.tape_max_ops < tape_ops_bound(launch) || launch.tape_overflow == nullptr) {
-            g_kernel_error = "the spectral tape is missing or too small for this wavefront launch";
-            return PYR_ERR_INVALID_ARGUMENT;
-        }
-        lds_logic = ((size_t)launch.spectrum_samples + 1 + kTapeEagerSlots) * BLOCK * sizeof(float) + (size_t)scene.lds_table_floats * sizeof(float) +
-                    ((size_t)launch.tape_programs_lds * 8 + kTapeEagerSlots) * sizeof(uint32_t);
-    }
-    const size_t lds_trav = (size_t)launch.stack_lds * BLOCK * sizeof(int);
-    if (lds_logic > 160 * 1024) {
-        g_kernel_error = "spectrum_samples need more than 160 KB of LDS per workgroup";
-        return PYR_ERR_UNSUPPORTED;
-    }
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(logic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logic);
-    if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(trav), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trav);
-    if (err != hipSuccess) {
-        g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
-        return PYR_ERR_DEVICE;
-    }
-    const uint32_t blocks = (pool.n + BLOCK - 1) / BLOCK;
-    const int trav_blocks_per_cu = std::max(1, std::min<int>(8, (int)((160 * 1024) / std::max<size_t>(lds_trav, 1))));
-    const uint32_t trav_grid = std::min<uint32_t>((uint32_t)num_cus * (uint32_t)trav_blocks_per_cu, blocks);
-    const uint32_t trav_waves = trav_grid * (BLOCK / 64);
-    const uint32_t reserve = std::max<uint32_t>(64, std::min<uint32_t>(2048, (pool.n / std::max<uint32_t>(trav_waves * 4, 1)) & ~63u));
-    hipLaunchKernelGGL(wf_init_kernel, dim3(blocks), dim3(BLOCK), 0, stream, pool, launch.chunk_begin);
-    // Rounds are launched in batches; the last logic kernel of a batch reports whether any path still holds a ray.
-    constexpr int kBatch = 8;
-    // every round advances every live path by one ray, and a sample traces at most bounces + 2 * light_samples rays
-    const uint64_t chunks = launch.chunk_end - launch.chunk_begin, waves = pool.n / 64u;
-    const uint64_t max_rounds = ((chunks + waves - 1) / waves) * ((uint64_t)launch.bounces + 2ull * launch.light_samples + 3ull) + kBatch; // + the round a finished path waits parked (tape form)
-    for (uint64_t round = 0;; round += kBatch) {
-        if (round > max_rounds) {
-            g_kernel_error = "wavefront render did not finish within its round bound";
-            return PYR_ERR_DEVICE;
-        }
-        for (int i = 0; i < kBatch; ++i) {
-            if (i == kBatch - 1) (void)hipMemsetAsync(pool.work_flag, 0, sizeof(uint32_t), stream);
-            hipLaunchKernelGGL(logic, dim3(blocks), dim3(BLOCK), lds_logic, stream, scene, launch, pool);
-            hipLaunchKernelGGL(trav, dim3(trav_grid), dim3(BLOCK), lds_trav, stream, scene, pool, reserve, launch.stack_lds, launch.counters);
-        }
-        err = hipMemcpyAsync((void*)host_flag, pool.work_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (err == hipSuccess) err = hipStreamSynchronize(stream);
-        if (err != hipSuccess) {
-            g_kernel_error = std::string("wavefront render: ") + hipGetErrorString(err);
-            return PYR_ERR_DEVICE;
-        }
-        if (*host_flag == 0) break;
     }
     return PYR_OK;
 }

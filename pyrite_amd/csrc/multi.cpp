@@ -44,6 +44,7 @@ typedef enum { ncclMax = 2 } ncclRedOp_t;
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -182,7 +183,7 @@ struct PyrComm {
     int rank = 0, num_ranks = 1, device = 0;
     ncclComm_t comm = nullptr; // nullptr for a communicator of one rank (unless PYRITE_FORCE_RCCL made a real one)
     bool owns_comm = true;
-    bool dead = false; // aborted after an error inside a collective: every later call fails
+    std::atomic<bool> dead{false}; // aborted after an error inside a collective: every later call fails. Atomic: a sibling rank's host thread may abort it (pyr_render_simple_multi)
     Grown window;      // this rank's blocks + one trailer grain
     Grown gathered;    // rank 0: the senders' blocks (each with its trailer), one after the other
     Grown agree;       // two words: this rank's status, the agreed one
@@ -195,12 +196,11 @@ struct PyrComm {
         std::memset(host_words, 0, sizeof(uint32_t) * (size_t)(2 + num_ranks));
         return PYR_OK;
     }
-    void abort_comm() {
-        if (comm && !dead) {
+    void abort_comm() { // exactly once per communicator, whichever thread gets here first
+        if (!dead.exchange(true) && comm) {
             Rccl* lib = rccl();
             if (lib->CommAbort) (void)lib->CommAbort(comm);
         }
-        dead = true;
     }
     void release() {
         window.release();
@@ -282,7 +282,7 @@ int pyr_comm_status(PyrComm* comm) {
         if (word == 0) continue;
         const std::string who = "rank " + std::to_string(r);
         if (word == kTrailerLaunchFailed) return api_fail(PYR_ERR_DEVICE, who + " could not launch its render: the gathered film is invalid");
-        if (word == 2) return api_fail(PYR_ERR_DEVICE, who + ": the split scheduler gave up waiting: the gathered film is invalid");
+        if (word == 2) return api_fail(PYR_ERR_DEVICE, who + ": a wave gave up waiting on its workgroup's LDS queues: the gathered film is invalid");
         return api_fail(PYR_ERR_DEVICE, who + ": a path appended more records than the spectral tape's bound allows: the gathered film is invalid");
     }
     return PYR_OK;
@@ -513,6 +513,11 @@ int pyr_render_simple_multi(PyrScene* const* scenes, uint32_t num_devices, const
         auto work = [&](uint32_t i) {
             status[i] = pyr_render_simple_sharded(&comms[i], scenes[i], camera, film, params, i == 0 ? film_dev : nullptr, streams[i]);
             if (status[i] != PYR_OK) messages[i] = pyr_last_error();
+            // A rank whose collective failed has aborted its own communicator; its siblings may already sit in an untimed
+            // hipStreamSynchronize on a gather that can no longer complete. Abort theirs from here, now -- ncclCommAbort is what
+            // unblocks them -- instead of after a join() that waits for those very threads.
+            if (use_rccl && comms[i].dead.load())
+                for (uint32_t j = 0; j < num_devices; ++j) comms[j].abort_comm();
             (void)hipSetDevice(devices[i]);
             if (hipStreamSynchronize(streams[i]) != hipSuccess && status[i] == PYR_OK) status[i] = PYR_ERR_DEVICE, messages[i] = "hipStreamSynchronize failed";
             if (status[i] == PYR_OK && (status[i] = pyr_comm_status(&comms[i])) != PYR_OK) messages[i] = pyr_last_error();
@@ -529,8 +534,8 @@ int pyr_render_simple_multi(PyrScene* const* scenes, uint32_t num_devices, const
         if (use_rccl && any_dead) { // the cached communicators are of no use any more: the next call makes new ones
             std::lock_guard<std::mutex> lock(cache_mutex);
             Rccl* lib = rccl();
-            for (uint32_t i = 0; i < num_devices; ++i)
-                if (!comms[i].dead && lib->CommAbort) (void)lib->CommAbort(comms[i].comm);
+            (void)lib;
+            for (uint32_t i = 0; i < num_devices; ++i) comms[i].abort_comm();
             cache.erase(devices);
         }
     } else {

@@ -49,7 +49,7 @@ def closed_box(albedo, emission, half=1.0):
     return World(flat)
 
 
-@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
+@pytest.mark.parametrize("scheduler", ["sync", "sm"])
 @pytest.mark.parametrize("light_samples,bounces", [(0, 8), (4, 8), (2, 3), (4, 1)])
 def test_furnace_closed_box_has_the_geometric_series_radiance(scheduler, light_samples, bounces, gpu_lib, monkeypatch):
     """Inside a closed box whose walls all emit E and reflect a Lambertian fraction rho, the radiance after B path segments is

@@ -133,7 +133,7 @@ def test_random_scene_matches_the_oracle_on_every_scheduler(seed, gpu_lib, monke
     cfilm = r.new_film(width, height)
     ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
     assert np.isfinite(cfilm.grains).all()
-    for scheduler in ("sync", "sm", "wf"):
+    for scheduler in ("sync", "sm"):
         monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
         gfilm = r.new_film(width, height)
         gcount = r.render(gfilm, cam, world, counters=True)
@@ -200,7 +200,7 @@ def test_random_soup_hits_and_film_match_the_oracle(seed, gpu_lib, monkeypatch):
     cam = Camera.from_project(camera.perspective(fov=60, transform=transform.look_at(**{"from": vector(0, -9, 1), "to": vector(0, 0, 0), "up": vector(z=1)})))
     cfilm = r.new_film(40, 30)
     oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
-    for scheduler in ("sm", "wf", "sync"):
+    for scheduler in ("sm", "sync"):
         monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
         gfilm = r.new_film(40, 30)
         r.render(gfilm, cam, world)

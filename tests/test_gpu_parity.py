@@ -120,11 +120,11 @@ def test_render_matches_the_oracle(name, gpu_lib):
         assert gcount[key] == ccount[key], key
 
 
-@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
+@pytest.mark.parametrize("scheduler", ["sync", "sm"])
 @pytest.mark.parametrize("name", ["c2_cornell", "lamps_example", "diamonds_example", "textures_example"])
 def test_all_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypatch):
-    """The bounce-synchronous walk, the stage-scheduled state machine and the wavefront pipeline are three schedules of the
-    same per-path work: all must reproduce the oracle (the library picks one per scene; PYRITE_SCHEDULER forces it)."""
+    """The bounce-synchronous walk and the stage-scheduled state machine are two schedules of the
+    same per-path work: both must reproduce the oracle (the library picks one per scene; PYRITE_SCHEDULER forces it)."""
     monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
     gfilm, cfilm, gcount, ccount = render_both(CASES[name](), 8, gpu_lib)
     assert_parity(gfilm, cfilm)
@@ -148,7 +148,7 @@ def test_vertical_image_single_wavelength_and_no_light_samples(gpu_lib):
     assert gfilm.total_weight() == 24 * 40 * 4
 
 
-@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
+@pytest.mark.parametrize("scheduler", ["sync", "sm"])
 def test_world_without_objects_is_all_sky(scheduler, gpu_lib, monkeypatch):
     """No primitives at all (the BVH is a root with two empty leaves): every path misses and shows the sky."""
     from pyrite_amd.project import light_source
@@ -309,52 +309,13 @@ def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
         assert gcount["exposures"] < gcount["samples"] * 10  # dispersed paths expose the hero wavelength only
 
 
-@pytest.mark.parametrize("glass", [False, True])
-def test_split_scheduler_on_a_c3_shaped_scene(glass, gpu_lib, monkeypatch):
-    """render_kernel_split (logic waves own the paths, traversal waves walk the tree, rays handed over in LDS slots) on the
-    C3 / C5-shaped scene: the oracle's film and path counters, ragged tiles, with and without the counters build. The scene
-    is big enough for the four-child tree with triangle pairs the scheduler requires (smaller ones run on the stage scheduler)."""
-    from pyrite_amd.renderer import Camera, Renderer, World
-
-    monkeypatch.setenv("PYRITE_SCHEDULER", "split")
-    monkeypatch.setenv("PYRITE_SCHEDULER_STRICT", "1")  # the split kernel itself, not its fallback to the stage scheduler
-    project = scenes.c3_mesh_in_box(width=50, height=30, pixel_samples=5, glass=glass, bounces=20 if glass else None)
-    world = World(scenes.c3_flat(segments=96, sides=48, glass=glass))
-    r = Renderer.from_project(project["renderer"], seed=13)
-    cam = Camera.from_project(project["camera"])
-    gfilm, plain, cfilm = r.new_film(50, 30), r.new_film(50, 30), r.new_film(50, 30)
-    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
-    gcount = r.render(gfilm, cam, world, counters=True)
-    r.render(plain, cam, world)
-    assert_parity(gfilm, cfilm)
-    assert_parity(plain, cfilm)
-    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
-        assert gcount[key] == ccount[key], key
+def test_stage_scheduler_on_an_lds_resident_scene_with_a_one_level_lds_stack(gpu_lib, monkeypatch):
+    """the kernels built for scenes staged in LDS have no scratch part of the traversal stack (one entry), so the
+    launcher must keep the WHOLE stack in LDS for such scenes whatever PYRITE_LDS_STACK or the budget say -- also when the
+    stage scheduler is forced onto a scene the synchronous walk would normally take."""
     monkeypatch.setenv("PYRITE_SCHEDULER", "sm")
-    sm_film = r.new_film(50, 30)
-    scount = r.render(sm_film, cam, world, counters=True)
-    assert scount == gcount  # the same steps, box for box: the traversal is the stage scheduler's
-    assert_parity(sm_film, gfilm)
-
-
-@pytest.mark.parametrize("slots", ["64", "640", ""])
-@pytest.mark.parametrize("glass", [False, True])
-def test_wavefront_scheduler_on_a_c3_shaped_scene(glass, slots, gpu_lib, monkeypatch):
-    """The wavefront pipeline with a pool smaller than / equal to / larger than the work (every slot walks its own strided
-    sample sequence), ragged tiles, counters on."""
-    from pyrite_amd.renderer import Camera, Renderer, World
-
-    monkeypatch.setenv("PYRITE_SCHEDULER", "wf")
-    if slots:
-        monkeypatch.setenv("PYRITE_WF_SLOTS", slots)
-    project = scenes.c3_mesh_in_box(width=50, height=30, pixel_samples=3, glass=glass, bounces=20 if glass else None)
-    world = World(scenes.c3_flat(segments=64, sides=32, glass=glass))
-    r = Renderer.from_project(project["renderer"], seed=11)
-    r.tile_size = 16
-    cam = Camera.from_project(project["camera"])
-    gfilm, cfilm = r.new_film(50, 30), r.new_film(50, 30)
-    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
-    gcount = r.render(gfilm, cam, world, counters=True)
+    monkeypatch.setenv("PYRITE_LDS_STACK", "1")
+    gfilm, cfilm, gcount, ccount = render_both(scenes.c2_cornell(48, 48, 6), 4, gpu_lib)
     assert_parity(gfilm, cfilm)
     for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
         assert gcount[key] == ccount[key], key
@@ -494,7 +455,7 @@ def test_tape_records_the_bound_and_no_more(gpu_lib, monkeypatch):
         assert_parity(gfilm, cfilm)
 
 
-@pytest.mark.parametrize("scheduler", ["sync", "sm", "wf"])
+@pytest.mark.parametrize("scheduler", ["sync", "sm"])
 def test_c1_with_the_reference_shaped_lamp_material(scheduler, gpu_lib, monkeypatch):
     """SURVEY 8(d) writes C1's lamp sphere as cornell.lua's `emissive + diffuse`. The config itself uses a purely emissive lamp
     (a diffuse hit ON a spherical lamp samples that lamp from its own surface: solid_angle_towards is None there and
