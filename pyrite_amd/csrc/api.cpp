@@ -17,10 +17,6 @@
 
 using namespace pyr;
 
-#ifndef PYR_QUANT_NODES
-#define PYR_QUANT_NODES 0
-#endif
-
 namespace {
 
 thread_local std::string g_error;
@@ -484,16 +480,8 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             }
     }
     if ((rc = s->pair_prims.upload(pairs.data(), pairs.size() * sizeof(DevPrimPair)))) return rc;
-#if PYR_QUANT_NODES // A/B build (bvh.h NodeQ64): both copies of the wide tree as 64-byte quantized nodes, same indices
-    {
-        const std::vector<NodeQ64> qp = quantize_wide(pair_nodes), qw = quantize_wide(wide.nodes);
-        if ((rc = s->wide_pair_nodes.upload(qp.data(), qp.size() * sizeof(NodeQ64)))) return rc;
-        if ((rc = s->wide_nodes.upload(qw.data(), qw.size() * sizeof(NodeQ64)))) return rc;
-    }
-#else
     if ((rc = s->wide_pair_nodes.upload(pair_nodes.data(), pair_nodes.size() * sizeof(Node128)))) return rc;
     if ((rc = s->wide_nodes.upload(wide.nodes.data(), wide.nodes.size() * sizeof(Node128)))) return rc;
-#endif
     if ((rc = s->prims.upload(prims.data(), prims.size() * sizeof(DevPrim)))) return rc;
     if ((rc = s->tri_shade.upload(shade.data(), shade.size() * sizeof(DevTriShade)))) return rc;
     if ((rc = s->spheres.upload(d->spheres, (size_t)d->num_spheres * 16))) return rc;
@@ -659,6 +647,8 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 1;
     else if (e && std::string(e) == "sync")
         L.scheduler = 0;
+    else if (e && std::string(e) == "px") // path-exchange scheduler (kernels.hip render_kernel_px); falls back to sm where it cannot run
+        L.scheduler = 2;
     else // the synchronous walk for scenes that live in LDS -- unless they run interpreter programs: the stage scheduler keeps the
          // interpreter in line and memoised (spheres example 572 -> 737, lamps 549 -> 724 Msamples/s against the synchronous walk)
         L.scheduler = scene_is_lds_resident(scene->dev) && scene->dev.needs_interpreter == 0 ? 0u : 1u;
@@ -667,11 +657,11 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     if (L.scheduler == 0 && scene->dev.needs_interpreter != 0) L.scheduler = 1;
     const char* lanes = std::getenv("PYRITE_SM_LANES");
     const char* steps = std::getenv("PYRITE_SM_STEPS");
-    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : 16u;
+    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : (L.scheduler == 2 ? 32u : 16u);
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;
-    if (L.scheduler == 1 && scene->dev.needs_interpreter == 0) {
+    if (L.scheduler != 0 && scene->dev.needs_interpreter == 0) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
         L.tape_max_ops = tape_ops_bound(L);
         int rc = reserve_tape(scene, L, stream);

@@ -299,42 +299,4 @@ WideBvh collapse_to_wide(const BuiltBvh& bvh) {
     return out;
 }
 
-std::vector<NodeQ64> quantize_wide(const std::vector<Node128>& nodes) {
-    std::vector<NodeQ64> out(nodes.size());
-    for (size_t n = 0; n < nodes.size(); ++n) {
-        const Node128& in = nodes[n];
-        NodeQ64& q = out[n];
-        const float* lo[3] = {in.lo_x, in.lo_y, in.lo_z};
-        const float* hi[3] = {in.hi_x, in.hi_y, in.hi_z};
-        uint8_t* qlo[3] = {q.lo_x, q.lo_y, q.lo_z};
-        uint8_t* qhi[3] = {q.hi_x, q.hi_y, q.hi_z};
-        for (int a = 0; a < 3; ++a) {
-            float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
-            for (int k = 0; k < 4; ++k)
-                if (in.child[k] != kEmptyChild) mn = std::min(mn, lo[a][k]), mx = std::max(mx, hi[a][k]);
-            if (!(mn <= mx)) mn = mx = 0.0f; // a node without children (the root of an empty scene)
-            const float origin = std::nextafter(mn, -std::numeric_limits<float>::infinity());
-            // 255 steps must reach the far side with room for the float rounding of origin + scale * 255 on the device
-            float scale = std::nextafter((float)(((double)mx - (double)origin) / 254.5), std::numeric_limits<float>::infinity());
-            scale = std::max(scale, 1.0e-20f);
-            q.origin[a] = origin, q.scale[a] = scale;
-            for (int k = 0; k < 4; ++k) {
-                if (in.child[k] == kEmptyChild) {
-                    qlo[a][k] = 255, qhi[a][k] = 0;
-                    continue;
-                }
-                // in double, against the float values the device multiplies: origin + scale * q_lo <= lo and origin + scale * q_hi >= hi
-                long l = (long)std::floor(((double)lo[a][k] - (double)origin) / (double)scale);
-                long h = (long)std::ceil(((double)hi[a][k] - (double)origin) / (double)scale);
-                while (l > 0 && (double)origin + (double)scale * (double)l > (double)lo[a][k]) --l;
-                while (h < 255 && (double)origin + (double)scale * (double)h < (double)hi[a][k]) ++h;
-                qlo[a][k] = (uint8_t)std::max(0l, std::min(255l, l));
-                qhi[a][k] = (uint8_t)std::max(0l, std::min(255l, h));
-            }
-        }
-        for (int k = 0; k < 4; ++k) q.child[k] = in.child[k];
-    }
-    return out;
-}
-
 } // namespace pyr

@@ -74,23 +74,6 @@ struct alignas(128) Node128 {
 static_assert(sizeof(Node128) == 128, "wide node must be 128 bytes");
 constexpr int32_t kEmptyChild = INT32_MIN;
 
-// The four-child node once more, quantized (VERDICT r3 item 4 / DESIGN 8c): 64 bytes = FOUR dwordx4 loads per visit instead of
-// seven. The children's planes are 8-bit offsets from the node's own lower corner, one dword per (axis, side) holding the four
-// children's bytes, so a lane still picks near / far planes by its ray's signs -- with a select on the dword instead of an
-// address -- and turns a byte into a distance with one v_cvt_f32_ubyteN and one fma: t = q * (scale * inv) + (origin - o) * inv.
-// Boxes only grow (lo rounded down, hi rounded up, on top of build_bvh's padding), so closest hits do not change. An unused
-// slot has child == kEmptyChild and an inverted box (lo 255, hi 0); the kernels also test the child code, because an inverted
-// box is not seen as such on an axis where the node is flat.
-//   vectors: (origin.xyz, scale.x) (scale.y, scale.z, lo_x[4], lo_y[4]) (lo_z[4], hi_x[4], hi_y[4], hi_z[4]) child[4]
-struct alignas(64) NodeQ64 {
-    float origin[3];
-    float scale[3];
-    uint8_t lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4];
-    int32_t child[4];
-};
-static_assert(sizeof(NodeQ64) == 64, "quantized wide node must be 64 bytes");
-std::vector<NodeQ64> quantize_wide(const std::vector<Node128>& nodes);
-
 struct WideBvh {
     std::vector<Node128> nodes; // nodes[0] is the root
     uint32_t max_depth = 0;     // node levels on the longest path

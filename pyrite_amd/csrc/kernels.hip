@@ -1395,7 +1395,7 @@ struct SyncProf {
     unsigned long long section[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
 };
 #ifdef PYR_PHASE_PROFILE
-__device__ unsigned long long g_phase_prof[16];
+__device__ unsigned long long g_phase_prof[32]; // [0..15] as tools/phase_profile.py reads them; [16..31] render_kernel_px seat census
 #define SLAP(sp, i)                                 \
     {                                               \
         const unsigned long long now_ = clock64();  \
@@ -1935,72 +1935,12 @@ DEV WidePlanes load_wide_planes(const float4* wide_nodes, const Trav& t) {
     const uint32_t ax = base + t.nx, ay = base + t.ny, az = base + t.nz;
     return WidePlanes{plane(ax), plane(ay + 16u), plane(az + 32u), plane(ax ^ 48u), plane((ay ^ 48u) + 16u), plane((az ^ 48u) + 32u), plane(base + 96u)};
 }
-#ifndef PYR_QUANT_NODES
-#define PYR_QUANT_NODES 0
-#endif
-// The box tests of one visit of a QUANTIZED four-child node (bvh.h NodeQ64, -DPYR_QUANT_NODES=1): four loads instead of seven.
-// Every plane is origin + scale * byte, so its distance along the ray is byte * (scale * inv) + (origin - o) * inv: one
-// v_cvt_f32_ubyteN and one (packed) fma per plane. Near / far planes by the ray's signs as in load_wide_planes, here a select
-// between the lo and hi dwords. Same outputs as wide_node_children: c[] the children that are hit, nearest first, e[] their
-// entry distances, INT32_MIN / +inf at the end.
-template <bool COUNT>
-DEV void wide_children_quantized(const float4* wide_nodes, const Trav& t, Counters& cnt, float (&e)[4], int (&c)[4]) {
-    const char* nodes = reinterpret_cast<const char*>(wide_nodes);
-    auto vec = [&](uint32_t byte_offset) { return *(global_f4v*)(nodes + byte_offset); };
-    const uint32_t base = (uint32_t)t.node << 6;
-    const f4v v0 = vec(base), v1 = vec(base + 16u), v2 = vec(base + 32u), v3 = vec(base + 48u);
-    const float ax = v0.w * t.inv.x, ay = v1.x * t.inv.y, az = v1.y * t.inv.z;
-    const float bx = (v0.x - t.o.x) * t.inv.x, by = (v0.y - t.o.y) * t.inv.y, bz = (v0.z - t.o.z) * t.inv.z;
-    const uint32_t lox = __float_as_uint(v1.z), loy = __float_as_uint(v1.w), loz = __float_as_uint(v2.x);
-    const uint32_t hix = __float_as_uint(v2.y), hiy = __float_as_uint(v2.z), hiz = __float_as_uint(v2.w);
-    const bool negx = t.nx != 0u, negy = t.ny != 0u, negz = t.nz != 0u; // trav_ray_signs: non-zero for a negative direction component
-    const uint32_t nearx = negx ? hix : lox, farx = negx ? lox : hix;
-    const uint32_t neary = negy ? hiy : loy, fary = negy ? loy : hiy;
-    const uint32_t nearz = negz ? hiz : loz, farz = negz ? loz : hiz;
-    c[0] = __float_as_int(v3.x), c[1] = __float_as_int(v3.y), c[2] = __float_as_int(v3.z), c[3] = __float_as_int(v3.w);
-    const f2v pax = {ax, ax}, pay = {ay, ay}, paz = {az, az}, pbx = {bx, bx}, pby = {by, by}, pbz = {bz, bz};
-    auto b0 = [](uint32_t w) { return (float)(w & 0xffu); };
-    auto b1 = [](uint32_t w) { return (float)((w >> 8) & 0xffu); };
-    auto b2 = [](uint32_t w) { return (float)((w >> 16) & 0xffu); };
-    auto b3 = [](uint32_t w) { return (float)(w >> 24); };
-    const f2v nx01 = __builtin_elementwise_fma((f2v){b0(nearx), b1(nearx)}, pax, pbx), nx23 = __builtin_elementwise_fma((f2v){b2(nearx), b3(nearx)}, pax, pbx);
-    const f2v ny01 = __builtin_elementwise_fma((f2v){b0(neary), b1(neary)}, pay, pby), ny23 = __builtin_elementwise_fma((f2v){b2(neary), b3(neary)}, pay, pby);
-    const f2v nz01 = __builtin_elementwise_fma((f2v){b0(nearz), b1(nearz)}, paz, pbz), nz23 = __builtin_elementwise_fma((f2v){b2(nearz), b3(nearz)}, paz, pbz);
-    const f2v fx01 = __builtin_elementwise_fma((f2v){b0(farx), b1(farx)}, pax, pbx), fx23 = __builtin_elementwise_fma((f2v){b2(farx), b3(farx)}, pax, pbx);
-    const f2v fy01 = __builtin_elementwise_fma((f2v){b0(fary), b1(fary)}, pay, pby), fy23 = __builtin_elementwise_fma((f2v){b2(fary), b3(fary)}, pay, pby);
-    const f2v fz01 = __builtin_elementwise_fma((f2v){b0(farz), b1(farz)}, paz, pbz), fz23 = __builtin_elementwise_fma((f2v){b2(farz), b3(farz)}, paz, pbz);
-    const float tn[4][3] = {{nx01.x, ny01.x, nz01.x}, {nx01.y, ny01.y, nz01.y}, {nx23.x, ny23.x, nz23.x}, {nx23.y, ny23.y, nz23.y}};
-    const float tf[4][3] = {{fx01.x, fy01.x, fz01.x}, {fx01.y, fy01.y, fz01.y}, {fx23.x, fy23.x, fz23.x}, {fx23.y, fy23.y, fz23.y}};
-    for (int k = 0; k < 4; ++k) {
-        const float tmin = fmaxf(fmaxf(tn[k][0], tn[k][1]), tn[k][2]);
-        const float tmax = fminf(fminf(tf[k][0], tf[k][1]), tf[k][2]);
-        const float entry = fmaxf(tmin, 0.0f);
-        if (COUNT) cnt.box_tests += c[k] != INT32_MIN ? 1u : 0u;
-        const bool hit = (tmax >= entry) & (entry < t.closest) & (c[k] != INT32_MIN); // an unused slot's inverted box is not one on an axis where the node is flat
-        e[k] = hit ? entry : PYR_INF;
-        c[k] = hit ? c[k] : INT32_MIN;
-    }
-    auto order = [&](int a, int b) {
-        const bool sw = e[b] < e[a];
-        const float ea = sw ? e[b] : e[a], eb = sw ? e[a] : e[b];
-        const int ca = sw ? c[b] : c[a], cb = sw ? c[a] : c[b];
-        e[a] = ea, e[b] = eb, c[a] = ca, c[b] = cb;
-    };
-    order(0, 1);
-    order(2, 3);
-    order(0, 2);
-    order(1, 3);
-    order(1, 2);
-}
-// c[] / e[] of the node a lane stands at, whichever node format the library is built for.
+// c[] / e[] of the node a lane stands at. (Round 4 measured a quantized 64-byte node here -- four loads per visit instead of
+// seven for +33 vector instructions: C3 -7 %, intersect_kernel +3 %, profiles/r04_c3_ta_tcp_counters.txt -- and deleted it.)
 template <bool COUNT>
 DEV void wide_children(const float4* wide_nodes, const Trav& t, Counters& cnt, float (&e)[4], int (&c)[4]) {
-#if PYR_QUANT_NODES
-    wide_children_quantized<COUNT>(wide_nodes, t, cnt, e, c);
-#else
     const WidePlanes pl = load_wide_planes(wide_nodes, t); // near / far planes picked by the ray's signs (trav_ray_signs)
     wide_node_children<COUNT, true>(pl.nx, pl.ny, pl.nz, pl.fx, pl.fy, pl.fz, pl.ch, t, cnt, e, c);
-#endif
 }
 template <bool COUNT, bool GLOBAL = true>
 DEV bool trav_step_wide(const SceneView& view, Trav& t, TravStack& stack, Counters& cnt) {
@@ -2692,8 +2632,8 @@ struct Walker {
 // (algorithm.rs:78). Consecutive records of one program (the light samples of one estimation) share one look-up, as in the
 // synchronous walk. Must be called by every lane of the wave.
 template <bool COUNT>
-DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wave_wl,
-                      uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
+DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wl_rows,
+                      uint32_t wl_column, uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = ballot64(exposing);
     const uint32_t n = (uint32_t)__popcll(mask);
@@ -2752,7 +2692,10 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         const float hero_wl = __shfl(p.wl, (int)src);
         const bool hero = k == SS - 1;
         const bool run = active;
-        const float wl = hero ? hero_wl : wave_wl[k * BLOCK + src];
+        // the companions' wavelengths live in the LDS column of the path's home (the lane itself in render_kernel_sm; wherever the
+        // path's sample sequence belongs in render_kernel_px, whose paths move between lanes)
+        const uint32_t src_column = (uint32_t)__shfl((int)wl_column, (int)src);
+        const float wl = hero ? hero_wl : wl_rows[k * BLOCK + src_column];
         float refl = 1.0f, bright = 0.0f, value = 0.0f;
         uint32_t value_of = 0xFFFFFFFFu;
         // A scene has few programs that read a spectrum (C3: three wall colours and the lamp). When they fit the LDS rows
@@ -2963,7 +2906,6 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
     Walker<COUNT, INTERP, TAPE> w;
     w.chunk = L.chunk_begin + blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     w.tape_prepared = nullptr;
-    const float* wave_wl = lds + (threadIdx.x & ~63u);
     uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
     // prepared programs for the replay: 8 words each, behind everything else in LDS
     uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0) + (LDS_TABLES ? S0.lds_table_floats : 0));
@@ -3001,7 +2943,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             const RenderLaunch& Lp = launch_from_kernarg(L);
             const DevScene Sp = scene_view(Lp);
-            if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, wave_wl, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+            if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
             w.expose_and_restart(Sp, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(ballot64(w.stage == ST_TRAV));
@@ -3057,6 +2999,339 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             PROF_END(3);
         }
     }
+    PROF_FLUSH();
+    flush_counters<COUNT>(cnt, L.counters);
+}
+
+// ------------------------------------------------------------------------------------------------ path-exchange scheduler
+// render_kernel_px (PYRITE_SCHEDULER=px): the stage-scheduled integrator with the PATHS of a
+// workgroup regrouped between its four waves. In render_kernel_sm a wave's 64 paths are spread over four stages and every
+// phase finds a fraction of the lanes (C3: traversal 33 / 64, SHADE 22, NEE 23). Here two waves of a workgroup only walk the
+// tree and two only run the logic phases (EXPOSE / SHADE / NEE), and a path moves to the other kind of wave whenever it changes
+// kind of work -- at a ray's start and at its end, when it has no traversal stack: 35 words through LDS. Unlike the split
+// scheduler of round 2 (which moved RAYS, kept the paths in the logic waves and so halved the paths in flight) every lane
+// of every wave is a seat that can hold a path: 256 paths per workgroup as before, the traversal seats all walking, the logic
+// seats all waiting for one of three pieces of logic.
+//   Homes. A path is the sample sequence of one of the workgroup's 256 "homes" (the lane numbers of render_kernel_sm): home h
+// walks chunks chunk_begin + 4 * block + h / 64, + total_waves, ... as lane h % 64, owns tape column 256 * block + h and the
+// LDS wavelength column h, whatever seat it sits in -- so every sample performs the operations of render_kernel_sm in the same
+// order and the films are identical.
+//   Queues. Two slot arrays in LDS (to the traversal waves / to the logic waves), kPxCap slots of a state word + kPxWords data
+// words each, [word][slot]. A lane with a path to hand over claims an EMPTY slot with a compare-and-swap (EMPTY -> WRITING),
+// writes the path, publishes it (FULL); a free seat of the other kind claims a FULL slot (-> READING), reads it, frees it
+// (EMPTY). Lanes probe slots (lane + 17 k) % kPxCap, so waves of one role do not fight over one slot. No order is kept: paths
+// are independent. LDS is in order per wave; release / acquire at workgroup scope keep the compiler honest.
+//   End. `live` counts homes whose sequence has not ended; every wave leaves when it reaches zero (no path exists then). No wave
+// waits for ever: idle turns are counted and past kPxSpinLimit the launch's error word is set (PYR_ERR_DEVICE).
+#ifndef PYR_PX_CAP
+#define PYR_PX_CAP 32
+#endif
+constexpr uint32_t kPxCap = PYR_PX_CAP, kPxWords = 35; // slots per queue: at most 64 (px_assign reads one slot's state per lane)
+constexpr uint32_t kPxQueueWords = kPxCap * (1 + kPxWords), kPxControlWords = 4;
+constexpr uint32_t kPxLdsWords = 2 * kPxQueueWords + kPxControlWords;
+constexpr uint32_t PX_EMPTY = 0u, PX_WRITING = 1u, PX_FULL = 2u, PX_READING = 3u;
+constexpr uint32_t ST_VACANT = 7u; // a seat without a path
+constexpr uint32_t kPxSpinLimit = 1u << 22;
+#ifndef PYR_PX_TRAV_STEPS
+#define PYR_PX_TRAV_STEPS 8
+#endif
+// Wave priorities of the two roles. NOT the stage scheduler's order: there every wave passes through every phase, here a role is
+// for life, and a logic wave at the bottom would be starved by the traversal waves it feeds.
+#ifndef PYR_PX_PRIO_T
+#define PYR_PX_PRIO_T 1
+#endif
+#ifndef PYR_PX_PRIO_E
+#define PYR_PX_PRIO_E 2
+#endif
+#ifndef PYR_PX_PRIO_S
+#define PYR_PX_PRIO_S 3
+#endif
+#ifndef PYR_PX_PRIO_N
+#define PYR_PX_PRIO_N 3
+#endif
+#ifndef PYR_PX_PATIENCE
+#define PYR_PX_PATIENCE 6 // turns a logic wave waits for a phase to reach its quorum before it runs the most wanted one with what it has
+#endif
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+template <class W>
+DEV void px_store(const W& w, uint32_t home, lds_u32* data, uint32_t slot) {
+    uint32_t k = 0;
+    auto put = [&](uint32_t v) { data[(k++) * kPxCap + slot] = v; };
+    auto putf = [&](float v) { put(__float_as_uint(v)); };
+    put(w.p.rng.x), put(w.p.rng.y), put(w.p.rng.z), put(w.p.rng.w);
+    put(w.p.pixel), putf(w.p.wl), put(w.chunk);
+    put(home | (w.p.events << 8) | (w.p.use_additional ? 1u << 16 : 0u) | (w.p.sample_light ? 1u << 17 : 0u) | (w.b_flip ? 1u << 18 : 0u) | (w.b_has_brdf ? 1u << 19 : 0u) |
+        (w.ls_pending ? 1u << 20 : 0u) | (w.ls_physical ? 1u << 21 : 0u) | (w.t.shadow ? 1u << 22 : 0u) | (w.t.blocked ? 1u << 23 : 0u));
+    put(w.nee_i), put(w.nee_lamp), put(w.p.bounce), put(w.n_ops);
+    putf(w.t.o.x), putf(w.t.o.y), putf(w.t.o.z), putf(w.t.d.x), putf(w.t.d.y), putf(w.t.d.z), putf(w.t.limit);
+    putf(w.t.closest), put(w.t.shape), putf(w.t.u), putf(w.t.v);
+    putf(w.b_normal.x), putf(w.b_normal.y), putf(w.b_normal.z), putf(w.b_out.x), putf(w.b_out.y), putf(w.b_out.z);
+    putf(w.ls_normal.x), putf(w.ls_normal.y), putf(w.ls_normal.z), putf(w.ls_scale), put(w.ls_material), put(w.ls_color);
+    static_assert(kPxWords == 35, "px_store / px_load move kPxWords words");
+}
+template <class W>
+DEV uint32_t px_load(W& w, const lds_u32* data, uint32_t slot) { // returns the path's home
+    uint32_t k = 0;
+    auto get = [&]() { return data[(k++) * kPxCap + slot]; };
+    auto getf = [&]() { return __uint_as_float(get()); };
+    w.p.rng.x = get(), w.p.rng.y = get(), w.p.rng.z = get(), w.p.rng.w = get();
+    w.p.pixel = get(), w.p.wl = getf(), w.chunk = get();
+    const uint32_t flags = get();
+    w.p.events = (flags >> 8) & 0xffu;
+    w.p.use_additional = (flags >> 16) & 1u, w.p.sample_light = (flags >> 17) & 1u, w.b_flip = (flags >> 18) & 1u, w.b_has_brdf = (flags >> 19) & 1u;
+    w.ls_pending = (flags >> 20) & 1u, w.ls_physical = (flags >> 21) & 1u, w.t.shadow = (flags >> 22) & 1u, w.t.blocked = (flags >> 23) & 1u;
+    w.nee_i = get(), w.nee_lamp = get(), w.p.bounce = get(), w.n_ops = get();
+    w.t.o.x = getf(), w.t.o.y = getf(), w.t.o.z = getf(), w.t.d.x = getf(), w.t.d.y = getf(), w.t.d.z = getf(), w.t.limit = getf();
+    w.t.closest = getf(), w.t.shape = get(), w.t.u = getf(), w.t.v = getf();
+    w.b_normal.x = getf(), w.b_normal.y = getf(), w.b_normal.z = getf(), w.b_out.x = getf(), w.b_out.y = getf(), w.b_out.z = getf();
+    w.ls_normal.x = getf(), w.ls_normal.y = getf(), w.ls_normal.z = getf(), w.ls_scale = getf(), w.ls_material = get(), w.ls_color = get();
+    w.b_position = w.t.o; // the bounce's position IS the origin of the shadow ray in flight (trace_direct); dead otherwise
+    return flags & 0xffu;
+}
+// The k-th lane of the wave that `wants` a slot in state `needed` gets the k-th slot that is in it (as the wave saw the states a
+// moment ago): the slots' lanes put their numbers down in rank order in the wave's scratch row, the wanting lanes pick theirs
+// up. kPxCap for a lane that gets none. Must be called by every lane of the wave. (Lanes probing fixed slots of their own --
+// the first form of this scheduler -- left a quarter of the traversal seats holding paths that found no slot while as many
+// seats stood vacant: profiles/r04_phase_profile_px.txt.)
+DEV uint32_t px_assign(bool wants, uint32_t needed, const lds_u32* state, uint32_t* wave_scratch, uint32_t lane) {
+    const unsigned long long wanting = ballot64(wants);
+    if (wanting == 0ull) return kPxCap;
+    const uint32_t mine = lane < kPxCap ? __hip_atomic_load(state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
+    const unsigned long long open = ballot64(mine == needed);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (mine == needed) wave_scratch[__popcll(open & below)] = lane;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t rank = (uint32_t)__popcll(wanting & below);
+    uint32_t slot = kPxCap;
+    if (wants && rank < (uint32_t)__popcll(open)) slot = wave_scratch[rank];
+    __builtin_amdgcn_wave_barrier();
+    return slot;
+}
+// Lanes that `want` to hand their path over: true for those whose path is in the queue now.
+template <class W>
+DEV bool px_push(bool wants, const W& w, uint32_t home, lds_u32* queue, uint32_t* wave_scratch, uint32_t lane) {
+    lds_u32* state = queue;
+    lds_u32* data = queue + kPxCap;
+    const uint32_t slot = px_assign(wants, PX_EMPTY, state, wave_scratch, lane);
+    bool sent = false;
+    if (slot < kPxCap) {
+        uint32_t expected = PX_EMPTY; // the other wave of this role may have taken it since
+        if (__hip_atomic_compare_exchange_strong(state + slot, &expected, PX_WRITING, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            px_store(w, home, data, slot);
+            __hip_atomic_store(state + slot, PX_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sent = true;
+        }
+    }
+    return sent;
+}
+// `vacant` seats: true for those that took a path (`home` set).
+template <class W>
+DEV bool px_pop(bool vacant, W& w, uint32_t& home, lds_u32* queue, uint32_t* wave_scratch, uint32_t lane) {
+    lds_u32* state = queue;
+    const lds_u32* data = queue + kPxCap;
+    const uint32_t slot = px_assign(vacant, PX_FULL, state, wave_scratch, lane);
+    bool got = false;
+    if (slot < kPxCap) {
+        uint32_t expected = PX_FULL;
+        if (__hip_atomic_compare_exchange_strong(state + slot, &expected, PX_READING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            home = px_load(w, data, slot);
+            __hip_atomic_store(state + slot, PX_EMPTY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            got = true;
+        }
+    }
+    return got;
+}
+
+template <bool COUNT, bool LDS_TABLES>
+__global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_px(DevScene S0, RenderLaunch L) {
+    extern __shared__ float lds[];
+    const uint32_t SS = L.spectrum_samples;
+    const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots;
+    TravStack stack;
+    int deep_levels[kMaxStackDepth];
+    stack.deep = deep_levels;
+    stack.lds = (lds_int*)(reinterpret_cast<int*>(lds + spectral_rows * BLOCK) + threadIdx.x);
+    stack.lds_entries = (int)L.stack_lds;
+    Counters cnt{};
+    const uint32_t lds_base_floats = (spectral_rows + L.stack_lds) * BLOCK;
+    const SceneView view = stage_scene<false>(S0, lds, lds_base_floats, true);
+    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t total_waves = gridDim.x * (BLOCK / 64);
+    const int phase_lanes = (int)L.sm_phase_lanes, expose_lanes = (int)L.sm_expose_lanes;
+    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
+    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_TABLES ? S0.lds_table_floats : 0));
+    float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
+    spectral_values[kTapeOneSlot * BLOCK] = 1.0f;
+    lds_u32* px = (lds_u32*)(prepared_lds + 8 * L.tape_programs_lds + kTapeEagerSlots);
+    lds_u32* to_trav = px;
+    lds_u32* to_logic = px + kPxQueueWords;
+    lds_u32* control = px + 2 * kPxQueueWords; // [0] homes whose sequence has not ended, [1] next home to start, [2] give up
+    for (uint32_t i = threadIdx.x; i < kPxLdsWords; i += BLOCK) px[i] = i == 2 * kPxQueueWords ? (uint32_t)BLOCK : 0u; // control[0]: every home is alive
+    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds); // ends with a barrier: the queues are clear behind it
+    // two of the four waves walk the tree; which two alternates with the workgroup's round on its CU, so that a SIMD -- wave w of
+    // every resident workgroup -- gets both kinds of wave
+    const bool trav_role = ((wave + (blockIdx.x >> 8)) & 1u) == 0u;
+    Walker<COUNT, false, true> w;
+    w.stage = ST_VACANT;
+    w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
+    uint32_t home = 0;
+    uint32_t idle_turns = 0, starved_turns = 0;
+    auto scene_view = [&](const RenderLaunch& Lp) {
+        const uint32_t rows = Lp.spectrum_samples + 1 + kTapeEagerSlots + Lp.stack_lds;
+        return stage_tables<LDS_TABLES ? 1 : 0, false>(scene_from_kernarg(S0), lds, rows * BLOCK);
+    };
+    auto alive = [&]() { return __hip_atomic_load(control + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; };
+    auto given_up = [&]() { return __hip_atomic_load(control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; };
+    // a turn in which a wave could do nothing at all; true when it is time to leave (the launch's error word is set then)
+    auto idle_turn = [&]() {
+        if (++idle_turns > kPxSpinLimit) {
+            *L.tape_overflow = 2u;
+            __hip_atomic_store(control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        return false;
+    };
+    PROF_DECL;
+    [[maybe_unused]] const unsigned long long t_wave0 = PROF_NOW();
+    [[maybe_unused]] unsigned long long t_exchange = 0;
+    [[maybe_unused]] unsigned long long census[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // PYR_PHASE_PROFILE: turns, and seats by state when a turn starts
+    if (trav_role) {
+        __builtin_amdgcn_s_setprio(PYR_PX_PRIO_T);
+        for (;;) {
+            // paths whose ray has ended go back to the logic waves; vacant seats take paths with a fresh ray
+            if (given_up()) break;
+            [[maybe_unused]] const unsigned long long t_x0 = PROF_NOW();
+            const bool finished = w.stage == ST_SHADE || w.stage == ST_NEE;
+            if (px_push(finished, w, home, to_logic, wave_list, lane)) w.stage = ST_VACANT;
+            if (px_pop(w.stage == ST_VACANT, w, home, to_trav, wave_list, lane)) {
+                w.stage = ST_TRAV;
+                w.t.node = 0, w.t.sp = 0; // trav_begin's restart, made by the logic wave; the tree's root
+            }
+            t_exchange += PROF_NOW() - t_x0;
+            const unsigned long long walking = ballot64(w.stage == ST_TRAV);
+#ifdef PYR_PHASE_PROFILE
+            census[0]++, census[1] += __popcll(walking), census[2] += __popcll(ballot64(w.stage == ST_VACANT)), census[3] += __popcll(ballot64(w.stage == ST_SHADE || w.stage == ST_NEE));
+#endif
+            if (walking == 0ull) { // nothing to walk: no work has arrived, or every seat waits for a slot of the queue back
+                if (!alive() || idle_turn()) break;
+                continue;
+            }
+            idle_turns = 0;
+#ifdef PYR_PHASE_PROFILE
+            const unsigned long long prof_t0_3 = clock64();
+#endif
+            w.t.inv = box_reciprocal(w.t.d);
+            trav_ray_signs(w.t);
+            for (int step = 0; step < PYR_PX_TRAV_STEPS; ++step) {
+                PROF_LANES(3, w.stage == ST_TRAV);
+                if (trav_step_lean<COUNT>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+            }
+            PROF_END(3);
+        }
+    } else {
+        for (;;) {
+            // ---- seats: take paths whose ray has ended; start the sequences of homes nobody has started yet
+            if (given_up()) break;
+            [[maybe_unused]] const unsigned long long t_x0 = PROF_NOW();
+            if (px_pop(w.stage == ST_VACANT, w, home, to_logic, wave_list, lane)) {
+                w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
+                w.tape_column = blockIdx.x * BLOCK + home;
+            }
+            {
+                const unsigned long long vacant = ballot64(w.stage == ST_VACANT);
+                if (vacant != 0ull && __hip_atomic_load(control + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)BLOCK) {
+                    uint32_t first = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(vacant)) first = __hip_atomic_fetch_add(control + 1, (uint32_t)__popcll(vacant), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    first = (uint32_t)__shfl((int)first, __builtin_ctzll(vacant));
+                    const uint32_t mine = first + (uint32_t)__popcll(vacant & ((1ull << lane) - 1ull));
+                    if (w.stage == ST_VACANT && mine < (uint32_t)BLOCK) {
+                        home = mine;
+                        w.stage = ST_NEW;
+                        w.chunk = L.chunk_begin + blockIdx.x * (BLOCK / 64) + (home >> 6);
+                        w.tape_column = blockIdx.x * BLOCK + home;
+                        w.n_ops = 0;
+                    }
+                }
+            }
+            t_exchange += PROF_NOW() - t_x0;
+            int nS = __popcll(ballot64(w.stage == ST_SHADE));
+            int nN = __popcll(ballot64(w.stage == ST_NEE));
+            int nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+            const int nW = __popcll(ballot64(w.stage == ST_TRAV)); // paths that wait for a slot of the traversal queue
+#ifdef PYR_PHASE_PROFILE
+            census[0]++, census[1] += nS, census[2] += nN, census[3] += nE, census[4] += nW, census[5] += __popcll(ballot64(w.stage == ST_VACANT));
+#endif
+            if (max(max(nS, nN), nE) == 0) { // no phase to run: every seat is vacant or waits for a slot of the traversal queue
+                if (nW == 0 && !alive()) break;
+                const bool sent = px_push(w.stage == ST_TRAV, w, home, to_trav, wave_list, lane);
+                if (sent) w.stage = ST_VACANT;
+                if (ballot64(sent) != 0ull)
+                    idle_turns = 0;
+                else if (idle_turn())
+                    break;
+                continue;
+            }
+            idle_turns = 0;
+            // A logic wave that waits issues nothing, so it waits for fuller phases: a phase runs when its quorum of lanes wants it;
+            // only after PYR_PX_PATIENCE turns without any does the most wanted one run with what it has.
+            if (nE < expose_lanes && nS < phase_lanes && nN < phase_lanes && starved_turns < PYR_PX_PATIENCE) {
+                starved_turns++;
+                const bool sent = px_push(w.stage == ST_TRAV, w, home, to_trav, wave_list, lane);
+                if (sent) w.stage = ST_VACANT;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            const bool impatient = starved_turns >= PYR_PX_PATIENCE;
+            starved_turns = 0;
+            Spectral spec{lds + home, SS};
+            if (nE >= expose_lanes || (impatient && nE != 0 && nE == max(max(nS, nN), nE))) {
+                __builtin_amdgcn_s_setprio(PYR_PX_PRIO_E);
+                PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
+                const RenderLaunch& Lp = launch_from_kernarg(L);
+                const DevScene Sp = scene_view(Lp);
+                replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, home, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+                const bool was_live = w.stage == ST_EXPOSE || w.stage == ST_NEW;
+                w.expose_and_restart(Sp, Lp, spec, cnt, home & 63u, total_waves);
+                const unsigned long long ended = ballot64(was_live && w.stage == ST_DONE);
+                if (ended != 0ull) { // these homes' sequences are over: their seats are vacant
+                    if (lane == (uint32_t)__builtin_ctzll(ended)) __hip_atomic_fetch_sub(control + 0, (uint32_t)__popcll(ended), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (w.stage == ST_DONE) w.stage = ST_VACANT;
+                }
+                PROF_END(0);
+                nS = __popcll(ballot64(w.stage == ST_SHADE));
+                nE = 0;
+            }
+            if (nS >= phase_lanes || (impatient && nS != 0 && nS == max(max(nS, nN), nE))) {
+                __builtin_amdgcn_s_setprio(PYR_PX_PRIO_S);
+                PROF_BEGIN(1, w.stage == ST_SHADE);
+                const RenderLaunch& Lp = launch_from_kernarg(L);
+                w.shade(scene_view(Lp), Lp, spec, cnt);
+                PROF_END(1);
+                nN = __popcll(ballot64(w.stage == ST_NEE));
+                nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
+                nS = 0;
+            }
+            if (nN >= phase_lanes || (impatient && nN != 0 && nN == max(max(nS, nN), nE))) {
+                __builtin_amdgcn_s_setprio(PYR_PX_PRIO_N);
+                PROF_BEGIN(2, w.stage == ST_NEE);
+                const RenderLaunch& Lp = launch_from_kernarg(L);
+                w.next_event(scene_view(Lp), Lp, spec, cnt);
+                PROF_END(2);
+            }
+            // ---- paths that now need a ray walked move to the traversal waves
+            [[maybe_unused]] const unsigned long long t_x1 = PROF_NOW();
+            if (px_push(w.stage == ST_TRAV, w, home, to_trav, wave_list, lane)) w.stage = ST_VACANT;
+            t_exchange += PROF_NOW() - t_x1;
+        }
+    }
+    PROF_EXTRA(trav_role ? 15 : 14, PROF_NOW() - t_wave0);
+    PROF_EXTRA(trav_role ? 12 : 13, t_exchange);
+#ifdef PYR_PHASE_PROFILE
+    for (int i = 0; i < 8; ++i) PROF_EXTRA((trav_role ? 16 : 24) + i, census[i]);
+#endif
     PROF_FLUSH();
     flush_counters<COUNT>(cnt, L.counters);
 }
@@ -3359,13 +3634,14 @@ uint32_t tape_ops_bound(const RenderLaunch& launch) { return 2u * launch.bounces
 uint32_t tape_lanes_bound(int num_cus) { return (uint32_t)num_cus * 8u * BLOCK; } // launch_render never starts more than 8 blocks per CU
 constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for the replay (4 KB); scenes with more use the HBM records
 static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_programs <= kTapeProgramsLds ? scene.num_programs : 0u; }
-static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return launch.scheduler == 1 && scene.needs_interpreter == 0; }
+static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return (launch.scheduler == 1 || launch.scheduler == 2) && scene.needs_interpreter == 0; }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
     size_t bytes = (spectral_rows + launch.stack_lds) * BLOCK * sizeof(float);
     if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
     bytes += (size_t)scene.lds_table_floats * sizeof(float);
     if (uses_tape(scene, launch)) bytes += ((size_t)tape_programs_in_lds(scene) * 8 + kTapeEagerSlots) * sizeof(uint32_t);
+    if (launch.scheduler == 2) bytes += (size_t)kPxLdsWords * sizeof(uint32_t); // render_kernel_px's two path queues
     return bytes;
 }
 
@@ -3403,7 +3679,11 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.stack_lds = 0;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernels are built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
-    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
+    // the path-exchange scheduler walks four-child trees with triangle pairs only and has no interpreter form: anything else
+    // runs on the stage scheduler
+    if (launch.scheduler == 2 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene))) launch.scheduler = 1;
+    launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
+    launch.stack_lds = launch.scheduler != 0 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
                                              : scene.stack_depth;
     // a scene staged in LDS is a few dozen nodes: its whole stack is kept in LDS (the kernels built for such scenes have no
     // scratch part: TravStack::deep is one entry), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below applies
@@ -3416,6 +3696,14 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
     RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0);
+    if (launch.scheduler == 2) {
+        static const RenderKernel px_variants[2][2] = {{render_kernel_px<false, false>, render_kernel_px<false, true>}, {render_kernel_px<true, false>, render_kernel_px<true, true>}};
+        kernel = px_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0];
+        if (launch.stack_lds < 4) {
+            g_kernel_error = "PYRITE_SCHEDULER=px needs at least four traversal stack levels in LDS";
+            return PYR_ERR_UNSUPPORTED;
+        }
+    }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
@@ -3486,6 +3774,15 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
 } // namespace pyr
 
 #ifdef PYR_PHASE_PROFILE
+extern "C" int pyr_debug_phase_profile32(unsigned long long* out32, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pyr::g_phase_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pyr::g_phase_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int pyr_debug_phase_profile(unsigned long long* out16, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pyr::g_phase_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;

@@ -23,10 +23,10 @@ else:
     project = scenes.c3_mesh_in_box(w, h, spp)
 world, cam, r, film = scenes.build(project, seed=1)
 lib = _lib.lib()
-fn = lib.pyr_debug_phase_profile
+fn = lib.pyr_debug_phase_profile32
 fn.restype = C.c_int
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 r.render(film, cam, world)  # warm up (BVH build, upload)
 fn(out, 1)
 t = time.time()
@@ -50,6 +50,11 @@ for i, name in enumerate(["EXPOSE/NEW", "SHADE", "NEE", "TRAV"]):
     per_turn = cyc[i] / (n / (int(os.environ.get("PYRITE_SM_STEPS", "8")) if i == 3 else 1))
     print("%-11s %5.1f %% of wave cycles | mean active lanes %5.1f / 64 | %8.0f cycles per turn | %.2f turns per sample"
           % (name, 100.0 * cyc[i] / total, lanes[i] / n, per_turn, turns[i] * 64.0 / samples / (8 if i == 3 else 1)))
-if any(out[12:16]):  # render_kernel_split: waves in two roles
-    print("split scheduler: logic waves idle %.1f %% of their cycles, traversal waves idle %.1f %%" % (100.0 * out[12] / max(out[14], 1), 100.0 * out[13] / max(out[15], 1)))
-    print("                 wave cycles logic %.3g, traversal %.3g" % (out[14], out[15]))
+if any(out[12:16]):  # render_kernel_px: waves in two roles
+    logic, trav = float(max(out[14], 1)), float(max(out[15], 1))
+    print("path exchange: traversal waves %.3g wave cycles: %.1f %% in traversal steps, %.1f %% exchanging paths, the rest waiting for work" % (trav, 100.0 * cyc[3] / trav, 100.0 * out[12] / trav))
+    print("               logic waves     %.3g wave cycles: %.1f %% in EXPOSE / SHADE / NEE, %.1f %% exchanging paths, the rest waiting for work" % (logic, 100.0 * sum(cyc[0:3]) / logic, 100.0 * out[13] / logic))
+    tt, lt = float(max(out[16], 1)), float(max(out[24], 1))
+    print("               seats of a traversal wave when a turn starts (%.0f turns): walking %.1f, vacant %.1f, ray ended and no slot in the queue back %.1f" % (tt, out[17] / tt, out[18] / tt, out[19] / tt))
+    print("               seats of a logic wave when a turn starts (%.0f turns): SHADE %.1f, NEE %.1f, EXPOSE / NEW %.1f, waiting for a slot of the traversal queue %.1f, vacant %.1f" % (
+        lt, out[25] / lt, out[26] / lt, out[27] / lt, out[28] / lt, out[29] / lt))
