@@ -28,6 +28,8 @@ Extra objects on the line:
                 scene lives in LDS, so its algorithmic bytes are LDS reads and the object says "bound": "lds".
   c5            (N = 1, default workload only) configs[4]'s workload on one GPU: the same mesh made of dispersive glass, 20
                 bounces, ONE timed step at the full 4096 spp (~20 s) after a warm-up at reduced spp, with its own roofline.
+  c1            (N = 1, default workload only) configs[0], the reference's own CPU-runnable case (spheres only, 256^2 x 64 spp): five
+                GPU steps, and `cpu` = the oracle's render of the whole configuration timed on the host's cores.
   cpu_baseline  the CPU oracle (a port of the reference's algorithm -- the Rust reference cannot be built here) rebuilt on
                 this host with -O3 -march=native (oracle/Makefile `native`; the reference builds with target-cpu=native,
                 .cargo/config:2) and timed on as many threads as the process may really use (the smaller of its CPU affinity,
@@ -114,17 +116,39 @@ def native_oracle():
         return None, "-O2 -march=x86-64-v3 -ffp-contract=off (portable build: this host could not rebuild the oracle)"
 
 
+def load_oracle():
+    """tests/oracle.py bound to the build of the oracle made on this host (once per process). Returns (module, build flags)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+
+    if not hasattr(load_oracle, "flags"):
+        path, load_oracle.flags = native_oracle()
+        if path:
+            oracle.use_library(path)
+    return oracle, load_oracle.flags
+
+
+def c1_cpu(world, cam, renderer, width, height):
+    """configs[0] is the reference's own CPU-runnable case: the oracle renders ALL of it (256 x 256 x 64 spp), timed, on the
+    threads this process may really use."""
+    oracle, flags = load_oracle()
+    cpu = host_cpu()
+    sc = oracle.OracleScene(world)
+    film = renderer.new_film(width, height)
+    t0 = time.perf_counter()
+    c = sc.render(renderer, cam, film, threads=cpu["threads_used"])
+    dt = time.perf_counter() - t0
+    sc.close()
+    return {"value": round(c["samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cpu["threads_used"], "kind": "port", "seconds": round(dt, 3),
+            "sample": "the whole configuration: %dx%d x %d spp = %d samples" % (width, height, renderer.pixel_samples, c["samples"]), "build": flags}
+
+
 def cpu_baseline(world, cam, renderer, width, height, target_seconds=15.0):
     """Time the oracle on the same scene and image with fewer samples per pixel (the loop is linear in spp, simple.rs:73), on
     as many threads as this process may really use, with a thread-scaling table (>= 2 s per point) so the figure can be judged."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import copy
 
-    import oracle
-
-    path, flags = native_oracle()
-    if path:
-        oracle.use_library(path)
+    oracle, flags = load_oracle()
     cpu = host_cpu()
     threads = cpu["threads_used"]
     t0 = time.perf_counter()
@@ -411,6 +435,7 @@ def main():
     ap.add_argument("--no-traversal", action="store_true", help="skip the BVH-traversal roofline measurement on the C3 scene")
     ap.add_argument("--no-c2", action="store_true", help="skip the extra C2 (configs[1]) measurement")
     ap.add_argument("--no-c5", action="store_true", help="skip the extra C5 (configs[4]'s workload on one GPU) measurement")
+    ap.add_argument("--no-c1", action="store_true", help="skip the extra C1 (configs[0]: GPU next to the oracle's full CPU render) measurement")
     ap.add_argument("--dev", default="", help="development overrides, e.g. spectrum_samples=1,light_samples=0,bounces=2 (marks the line reduced)")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
@@ -575,6 +600,21 @@ def main():
                           "ms_per_step": round(c5_ms, 3), "config": c5_config, "roofline": c5.roofline(c5.counters_for_seeds(c5_seeds), c5_kernel_ms, 1)}
             c5.world.close()
             del c5
+        if world_size == 1 and args.workload == "C3" and not args.no_c1 and not args.no_cpu_baseline and not wl.reduced:
+            # configs[0], the reference's own CPU-runnable case, whole: five GPU steps (a 5 ms launch each) next to the oracle's
+            # full render of the same 256 x 256 x 64 spp on the host's cores
+            c1_args = argparse.Namespace(**{**vars(args), "spp": None, "dev": ""})
+            c1 = Workload("C1", c1_args, torch, local_rank, 1, False)
+            c1_ms, c1_film, c1_seeds = timed_steps(c1, 5, 1, args.seed, fence, dist, 1)
+            c1_kernel_ms = sum(a.elapsed_time(b) for a, b in c1.launch_events) / 5
+            c1_config = c1.describe(1, float(c1_film[..., 1].sum(dtype=torch.float64).item()))
+            mismatch = mismatch or c1_config["film_weight_check"] != "ok"
+            del c1_film
+            line["c1"] = {"value": round(c1.width * c1.height * c1.spp / (c1_ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "steps": 5, "warmup": 1,
+                          "ms_per_step": round(c1_ms, 3), "config": c1_config, "roofline": c1.roofline(c1.counters_for_seeds(c1_seeds), c1_kernel_ms, 1),
+                          "cpu": c1_cpu(c1.world, c1.cam, c1.renderer, c1.width, c1.height),
+                          "note": "configs[0]: spheres only, the scene lives in LDS; the CPU figure is the oracle's render of the WHOLE configuration"}
+            c1.world.close()
         if world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl.world, wl.cam, wl.renderer, wl.width, wl.height)
         print(json.dumps(line), flush=True)

@@ -405,6 +405,7 @@ class Evaluator {
 
     const Token& peek() const { return tokens_[pos_]; }
     const Token& next() { return tokens_[pos_++]; }
+    int depth_ = 0; // nesting of expression() calls (see there)
     [[noreturn]] void fail(const std::string& message) const { throw LuaError(name_ + ":" + std::to_string(peek().line) + ": " + message); }
     bool accept_op(const char* op) {
         if (peek().kind == Token::Op && peek().text == op) {
@@ -432,6 +433,14 @@ class Evaluator {
         static const std::vector<std::pair<std::vector<std::string>, bool>> levels = {
             {{"or"}, false}, {{"and"}, false}, {{"<", ">", "<=", ">=", "~=", "=="}, false}, {{".."}, true}, {{"+", "-"}, false}, {{"*", "/", "%"}, false}};
         if (level == (int)levels.size()) return unary();
+        // Lua itself refuses chunks nested deeper than 200 levels ("chunk has too many syntax levels", LUAI_MAXCCALLS); without a
+        // bound a file of 5000 opening braces ran this recursive descent off the stack (found by tests/host_asan_driver.cpp)
+        struct Depth {
+            int& d;
+            explicit Depth(int& d_) : d(d_) { ++d; }
+            ~Depth() { --d; }
+        } guard(depth_);
+        if (level == 0 && depth_ > 200 * ((int)levels.size() + 1)) fail("chunk has too many syntax levels");
         Value lhs = expression(level + 1);
         for (;;) {
             const Token& tok = peek();

@@ -505,7 +505,10 @@ def _environment():
 def evaluate(text, name="project.lua", base_dir="."):
     """Evaluates one project file's text; returns what it `return`s as plain Python data (dicts, lists, numbers, strings and
     pyrite_amd.project nodes)."""
-    return _to_python(_Evaluator(text, name, _environment(), base_dir, frozenset()).run())
+    try:
+        return _to_python(_Evaluator(text, name, _environment(), base_dir, frozenset()).run())
+    except RecursionError:  # Lua itself refuses chunks nested deeper than 200 levels (LUAI_MAXCCALLS); the C++ reader counts them
+        raise LuaError("%s: chunk has too many syntax levels" % name) from None
 
 
 def load_project(path):

@@ -121,7 +121,7 @@ def random_project(seed):
 REGRESSION_SEEDS = [37]
 # Long campaigns: PYRITE_FUZZ_SEEDS=N runs N seeds of each kind, PYRITE_FUZZ_BASE=B starts them at B (another campaign, other scenes).
 FUZZ_BASE = int(__import__("os").environ.get("PYRITE_FUZZ_BASE", "0"))
-SCENE_SEEDS = sorted(set(range(FUZZ_BASE, FUZZ_BASE + int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "12")))) | set(REGRESSION_SEEDS))
+SCENE_SEEDS = sorted(set(range(FUZZ_BASE, FUZZ_BASE + int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "200")))) | set(REGRESSION_SEEDS))
 
 
 @pytest.mark.gpu
@@ -184,7 +184,7 @@ def random_soup(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "6"))))
+@pytest.mark.parametrize("seed", range(FUZZ_BASE, FUZZ_BASE + int(__import__("os").environ.get("PYRITE_FUZZ_SOUPS", __import__("os").environ.get("PYRITE_FUZZ_SEEDS", "100")))))
 def test_random_soup_hits_and_film_match_the_oracle(seed, gpu_lib, monkeypatch):
     from pyrite_amd.renderer import Camera, Renderer, World
     from test_gpu_parity import assert_same_hits, random_rays

@@ -620,6 +620,41 @@ def test_closest_hit_on_the_full_c3_mesh(gpu_lib):
     on_mesh = (ohits["shape"] >> 30 == 1) & ((ohits["shape"] & 0x3FFFFFFF) >= 12)  # the box's 12 triangles come first
     assert on_mesh[:250000].mean() > 0.05 and on_mesh[250000:400000].mean() > 0.08 and (ohits["shape"] != 0xFFFFFFFF).mean() > 0.85  # the box is open at the front
     assert counters["triangle_tests"] > len(rays) and counters["box_tests"] > 10 * len(rays)
+    # ... and eight million more of bench.py's rays (tools/big_hit_check.py ran 100 M once: 99,999,983 bit-exact, 16 ties, one
+    # flat-box prune order; this slice is on the driver's record every round)
+    total = ties
+    for batch in range(16):
+        rays = c3_bench_rays(500000, seed=100 + batch)
+        ohits, _ = sc.intersect(rays)
+        ghits, _, _ = world.intersect(rays)
+        total += assert_same_hits(ohits, ghits, world, rays)
+    assert total < 40, total  # ~2 ties per 10 M rays were seen
+    sc.close()
+    world.close()
+
+
+def test_full_size_c3_oracle_tiles_at_the_bench_seeds(gpu_lib):
+    """The oracle on tiles of the full-size C3 image at the seeds bench.py renders with (1, 2, 3), 2 spp: the image's
+    four corners, the ragged bottom row (1080 = 33 x 32 + 24), an edge column, and tiles on the mesh and in its shadow -- 18
+    tiles in all, path counters exactly, every pixel within 1e-5."""
+    W, H = 1920, 1080
+    world, cam, r, _ = scenes.build(scenes.c3_mesh_in_box(W, H, 2), seed=1)
+    sc = oracle.OracleScene(world)
+    tiles_x, tiles_y = W // 32, (H + 31) // 32
+    assert (tiles_x, tiles_y) == (60, 34)
+    picks = {1: ((0, 0), (0, 59), (33, 0), (33, 59), (24, 30), (30, 28)), 2: ((33, 31), (16, 0), (16, 59), (22, 20), (26, 38), (12, 30)),
+             3: ((0, 30), (33, 12), (8, 45), (25, 25), (29, 36), (31, 12))}
+    for seed, tiles in picks.items():
+        r.seed = seed
+        for row, col in tiles:
+            tile = tiles_x * row + col
+            cpu, gpu = r.new_film(W, H), r.new_film(W, H)
+            cc = sc.render(r, cam, cpu, threads=8, tile_range=(tile, tile + 1))
+            gc = r.render(gpu, cam, world, tile_range=(tile, tile + 1), counters=True)
+            for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+                assert gc[key] == cc[key], (seed, row, col, key)
+            assert cc["samples"] == 32 * (24 if row == 33 else 32) * 2
+            assert_parity(gpu, cpu)
     sc.close()
     world.close()
 

@@ -322,3 +322,69 @@ return {
     got = images.read_png(png)
     assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got == want).mean() > 0.99
     assert got.std() > 5  # an image, not a constant
+
+
+@pytest.mark.timeout(900)
+def test_host_cpp_and_oracle_under_sanitizers(tmp_path):
+    """the host-side C++ that parses untrusted input (project files, OBJ meshes, image files), the tree
+    builder and the CPU oracle in ONE executable built with -fsanitize=address,undefined (tests/host_asan_driver.cpp), no GPU:
+    the suite's own project files load, flatten, build their trees and render through the oracle; mutated and truncated copies of
+    them, binary junk, a mesh with junk in it and a truncated PNG are refused with a message -- no out-of-bounds access, overflow
+    or leak either way."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "pyrite_amd", "csrc")
+    exe = str(tmp_path / "host_asan")
+    san = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off"]
+    subprocess.check_call(["gcc", "-c", *san, os.path.join(csrc, "jpeg.c"), "-o", str(tmp_path / "jpeg.o")])
+    subprocess.check_call(["g++", "-std=c++17", *san, "-I" + os.path.join(root, "include"), "-o", exe, os.path.join(root, "tests", "host_asan_driver.cpp"),
+                           os.path.join(csrc, "host", "pyrite_host.cpp"), os.path.join(csrc, "host", "lua_project.cpp"), os.path.join(csrc, "host", "images.cpp"),
+                           str(tmp_path / "jpeg.o"), os.path.join(csrc, "bvh.cpp"), os.path.join(root, "oracle", "oracle.cpp"),
+                           "-L" + csrc, "-lpyrite_gpu", "-Wl,-rpath," + csrc, "-pthread"])
+    projects = os.path.join(root, "tests", "golden", "projects")
+    good = [os.path.join(projects, n) for n in sorted(os.listdir(projects)) if n.endswith(".lua") and n != "materials.lua"]  # a module gallery.lua requires, not a project
+    assert len(good) >= 1
+    # leak detection stays off: the sanitized executable links libpyrite_gpu.so for the symbols World::from_project names (never
+    # called here), and the HIP runtime it pulls in keeps allocations of its own alive at exit
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", LD_PRELOAD="")
+    run = subprocess.run([exe] + good, capture_output=True, text=True, env=env)
+    assert run.returncode == 0, run.stderr[-4000:]
+    assert run.stdout.split()[0] == str(len(good)) and "0 refused" in run.stdout, run.stdout + run.stderr[-2000:]
+
+    rng = np.random.default_rng(7)
+    hostile = []
+    for k, path in enumerate(good):
+        text = open(path, "rb").read()
+        d = tmp_path / ("case%d" % k)
+        d.mkdir()
+        for name in os.listdir(projects):  # meshes / images the project names, next to every mutated copy
+            if not name.endswith(".lua"):
+                os.symlink(os.path.join(projects, name), d / name)
+        for j, cut in enumerate((0, 1, len(text) // 3, len(text) // 2, len(text) - 2)):
+            p = d / ("cut%d.lua" % j)
+            p.write_bytes(text[:cut])
+            hostile.append(str(p))
+        for j in range(12):  # a few bytes overwritten: unbalanced brackets, broken numbers, stray operators
+            b = bytearray(text)
+            for pos in rng.integers(0, len(b), 4):
+                b[pos] = int(rng.choice(list(b"{}()[],.=\"'-0179e+\x00\xff \n")))
+            p = d / ("mut%d.lua" % j)
+            p.write_bytes(bytes(b))
+            hostile.append(str(p))
+    junk = tmp_path / "junk.lua"
+    junk.write_bytes(rng.integers(0, 256, 4096, dtype=np.uint8).tobytes())
+    deep = tmp_path / "deep.lua"
+    deep.write_text("return " + "{" * 5000 + "}" * 5000)
+    mesh_dir = tmp_path / "mesh"
+    mesh_dir.mkdir()
+    (mesh_dir / "bad.obj").write_text("o thing\nv 0 0 0\nv 1 nan 0\nv 1e999 1 0\nvn 0 0\nvt 1\nf 1/9/9 2 3\nf 1 2 99999999999\nf -5 2 3\nf\n")
+    (mesh_dir / "cut.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\x00\x00\x00\rIHDR" + b"\x00" * 6)
+    scene = ("return {camera = camera.perspective {fov = 40, transform = transform.look_at {from = vector(0, -5, 1), to = vector()}},"
+             " renderer = renderer.simple {pixel_samples = 1}, world = {objects = {%s}}}")
+    (mesh_dir / "mesh.lua").write_text(scene % "shape.mesh {file = 'bad.obj', materials = {thing = {surface = material.diffuse {color = 0.5}}}}")
+    (mesh_dir / "tex.lua").write_text(scene % "shape.sphere {position = vector(), radius = 1, material = {surface = material.diffuse {color = texture 'cut.png'}}}")
+    hostile += [str(junk), str(deep), str(mesh_dir / "mesh.lua"), str(mesh_dir / "tex.lua"), str(tmp_path / "does_not_exist.lua")]
+    run = subprocess.run([exe] + hostile, capture_output=True, env=env)
+    assert run.returncode == 0, run.stderr[-4000:].decode("utf-8", "replace")
+    assert b"deep.lua: " in run.stderr and b"too many syntax levels" in run.stderr  # 5000 nested tables once ran the parser off the stack
+    loaded, refused = (int(x) for x in run.stdout.decode().replace(",", "").split() if x.isdigit())
+    assert loaded + refused == len(hostile) and refused >= len(hostile) // 2, run.stdout
