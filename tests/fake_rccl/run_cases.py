@@ -141,4 +141,42 @@ def _():
 
 
 world.close()
+
+# ---- the plan the driver's 8-GPU run executes, at its real size: BASELINE's C3 image, 1920 x 1080 = 2040 ringed
+# tile blocks, eight ranks of 255 blocks = 151 MB each -- rank 0 posts seven receives (1.06 GB in ONE group, every message
+# under the 256 MiB the gather cuts at), the others one send each -- on the full 819,212-triangle mesh at 2 spp
+if os.environ.get("FAKE_RCCL_SKIP_FULL_SIZE") != "1":
+    W, H = 1920, 1080
+    big_world, big_cam, big_r, big_whole = scenes.build(scenes.c3_mesh_in_box(W, H, 2), seed=3)
+    big_r.render(big_whole, big_cam, big_world)
+
+    @case("eight_ranks_at_full_size_c3_equal_one_launch")
+    def _():
+        film = big_r.new_film(W, H)
+        big_r.render_multi(film, big_cam, big_world, devices=[0] * 8)
+        assert np.array_equal(film.grains[..., 1], big_whole.grains[..., 1]), "weights differ from the single launch"
+        assert np.allclose(film.grains[..., 0], big_whole.grains[..., 0], rtol=1e-4, atol=1e-6), "film differs from the single launch"
+
+    @case("a_message_lost_mid_group_at_full_size_fails_every_rank_at_once")
+    def _():
+        os.environ["FAKE_RCCL_DROP_SEND_FROM"] = "3"  # rank 0 holds six arrived messages of seven when its group fails
+        t = time.time()
+        try:
+            film = big_r.new_film(W, H)
+            try:
+                big_r.render_multi(film, big_cam, big_world, devices=[0] * 8)
+            except PyriteGpuError as e:
+                assert "ncclGroupEnd" in str(e) or "ncclRecv" in str(e), "wrong error: %s" % e
+            else:
+                raise AssertionError("the call returned PYR_OK")
+        finally:
+            del os.environ["FAKE_RCCL_DROP_SEND_FROM"]
+        # the stand-in's own timeout is 5 s (where RCCL would block for ever); the failing rank aborts its siblings' communicators
+        # as soon as it knows, so nobody sits out a second one
+        assert time.time() - t < 40, "took %.0f s" % (time.time() - t)
+        film = big_r.new_film(W, H)
+        big_r.render_multi(film, big_cam, big_world, devices=[0] * 8)  # new communicators were made
+        assert np.array_equal(film.grains[..., 1], big_whole.grains[..., 1])
+
+    big_world.close()
 print(json.dumps(results))
