@@ -2225,6 +2225,11 @@ constexpr uint32_t TAPE_EAGER_ADD = 1u << 31, TAPE_EAGER_SLOT_SHIFT = 8, TAPE_EA
 constexpr uint32_t kTapeOneSlot = kTapeEagerSlots - 1; // the value row that holds 1.0
 static_assert(BLOCK == 1u << TAPE_EAGER_SLOT_SHIFT, "an eager record's slot field is an index into rows of BLOCK floats");
 
+// Where record `op` of tape column `column` lives: [op][column], a row of one record index is contiguous (512 B per wave).
+// (Round 4 tried [op / 4][column][op % 4] -- a path's four consecutive records in one 32-byte sector, read back as two dwordx4:
+// the 8-byte stores do NOT merge in L2 before they are written back, the neighbouring lanes' records no longer share a sector
+// either, and the fabric saw 85 GB instead of 68 GB per 32-spp frame: C3 -3.5 %, profiles/r04_write_traffic_split.txt.)
+DEV size_t tape_index(uint32_t op, uint32_t lanes, uint32_t column) { return (size_t)op * lanes + column; }
 template <bool COUNT, bool INTERP, bool TAPE = false>
 struct Walker {
     uint32_t stage = ST_NEW;
@@ -2252,7 +2257,7 @@ struct Walker {
                 }
                 word = (kind == TAPE_ADD ? TAPE_EAGER_ADD : 0u) | (hero_only ? TAPE_HERO_ONLY : 0u) | (slot << TAPE_EAGER_SLOT_SHIFT);
             }
-            L.tape[(size_t)n_ops * L.tape_lanes + tape_column] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
+            L.tape[tape_index(n_ops, L.tape_lanes, tape_column)] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
         }
 #ifndef PYR_TAPE_NOSTORE
         else {
@@ -2668,7 +2673,6 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     // lane loads its own column's record -- one coalesced load per row, eight rows in flight -- and an item takes the record of
     // the lane it replays with a cross-lane read. (Reading record after record of one column from the item's lane was a chain
     // of dependent HBM round trips: it took a quarter of the render.) Lanes that are not being replayed load nothing.
-    const unsigned long long* my_column = L.tape + tape_column;
     // Rows past the end of a tape read as the identity record of the eager form -- "reflectance *= value[one] * 1.0", and
     // x * 1.0 is x bit for bit -- so the straight-line replay needs no "is this row still on my tape" test per record.
     const bool eager_form = n_spectral != 0;
@@ -2746,7 +2750,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
             unsigned long long rows[ROWS];
 #pragma unroll
-            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < my_ops ? my_column[(size_t)(r0 + j) * L.tape_lanes] : past_the_end;
+            for (uint32_t j = 0; j < ROWS; ++j) rows[j] = r0 + j < my_ops ? L.tape[tape_index(r0 + j, L.tape_lanes, tape_column)] : past_the_end;
             // all cross-lane reads of the batch first (one wait), then, in the eager form, all value reads (one more)
             uint32_t words[ROWS];
             float factors[ROWS];
