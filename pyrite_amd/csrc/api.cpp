@@ -167,10 +167,27 @@ DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
     o.output_kind = p.output_kind;
     o.output_reg = p.output_reg;
     o.fast = FAST_NONE;
+    o.tape_form = TAPE_FORM_DIRECT;
     if (p.kind != PYR_PROGRAM_INSTRUCTIONS) return o;
     const PyrInstr* I = d->instrs + p.first_instr;
     for (uint32_t k = 0; k < p.num_instrs; ++k)
         if (instr_reads_wavelength(I[k])) o.reads_wavelength = 1;
+    // the tape form of a program the interpreter has to run (device_scene.h TapeForm); a fast shape found below is DIRECT again
+    {
+        auto depends_on_wavelength = [&](const PyrInstr& ins) { return (ins.deps & PYR_DEP_WAVELENGTH) != 0u || instr_reads_wavelength(ins); };
+        uint32_t dependent = 0;
+        for (uint32_t k = 0; k < p.num_instrs; ++k) dependent += depends_on_wavelength(I[k]) ? 1u : 0u;
+        o.tape_form = TAPE_FORM_NONE;
+        if (p.output_kind == PYR_OUTPUT_NUMBER && p.num_instrs != 0) {
+            const PyrInstr& last = I[p.num_instrs - 1];
+            if (dependent == 0)
+                o.tape_form = TAPE_FORM_HIT_VALUE;
+            else if (dependent == 1 && last.op == PYR_OP_RGB_SPECTRUM && operand_is_wavelength(last.x) && last.output == p.output_reg) {
+                o.tape_form = TAPE_FORM_HIT_RGB;
+                o.tape_rgb_reg = last.a;
+            }
+        }
+    }
     auto is_spectrum = [&](const PyrInstr& ins) { return ins.op == PYR_OP_SPECTRUM && operand_is_wavelength(ins.x); };
     auto is_mul = [&](const PyrInstr& ins) { return ins.op == PYR_OP_BINARY && ins.value_type == PYR_VT_NUMBER && ins.operator_ == PYR_BIN_MUL; };
     if (p.output_kind != PYR_OUTPUT_NUMBER) return o;
@@ -189,6 +206,7 @@ DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
             o.fast_scale = bits_to_float(I[0].x.bits);
         }
     }
+    if (o.fast != FAST_NONE) o.tape_form = TAPE_FORM_DIRECT;
     return o;
 }
 
@@ -544,6 +562,31 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     }
     v.needs_interpreter = needs_interpreter ? 1u : 0u;
     v.uses_textures = uses_textures ? 1u : 0u;
+    // Round 4: the spectral tape for scenes WITH interpreter programs (device_scene.h TapeForm). Every colour program -- of a
+    // component, of a lamp, the sky -- must have a tape form; the value slots the replay keeps in LDS (kTapeEagerSlots = 8: one
+    // holds 1.0, three the RGB basis when a HIT_RGB program exists) must hold every spectrum-reading fast program (counted here
+    // without the sharing the kernel finds, so never fewer), and the prepared programs must fit their LDS table (128).
+    v.hit_tape = v.rgb_records = 0;
+    if (needs_interpreter) {
+        bool ok = d->num_programs <= 128;
+        uint32_t fast_programs = 0;
+        for (const DevProgram& pr : programs) fast_programs += pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast != FAST_NONE ? 1u : 0u;
+        auto colour = [&](uint32_t id) {
+            if (id >= programs.size()) return;
+            const DevProgram& pr = programs[id];
+            if (pr.kind != PYR_PROGRAM_INSTRUCTIONS) return;
+            if (pr.tape_form == TAPE_FORM_NONE) ok = false;
+            if (pr.tape_form == TAPE_FORM_HIT_RGB) v.rgb_records = 1u;
+        };
+        for (uint32_t i = 0; i < d->num_components; ++i) colour(d->components[i].color_program);
+        for (const DevLamp& l : lamps) colour(l.color_program);
+        colour(d->sky_program);
+        if (fast_programs + (v.rgb_records ? 3u : 0u) > 7u) ok = false;
+        const char* off = std::getenv("PYRITE_HIT_TAPE"); // A/B and tests: PYRITE_HIT_TAPE=0 keeps the online form (read at scene creation)
+        if (off && off[0] == '0') ok = false;
+        v.hit_tape = ok ? 1u : 0u;
+        if (!ok) v.rgb_records = 0u;
+    }
     v.hero_only_records = 0;
     for (uint32_t i = 0; i < d->num_materials; ++i)
         for (uint32_t k = 0; k < d->materials[i].num_emissive; ++k) {
@@ -661,9 +704,9 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;
-    if (L.scheduler != 0 && scene->dev.needs_interpreter == 0) {
+    if (L.scheduler != 0 && (scene->dev.needs_interpreter == 0 || uses_hit_tape(scene->dev, L))) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
-        L.tape_max_ops = tape_ops_bound(L);
+        L.tape_max_ops = tape_ops_bound(scene->dev, L);
         int rc = reserve_tape(scene, L, stream);
         if (rc != PYR_OK) return rc;
     }

@@ -62,6 +62,17 @@ enum FastProgram : uint32_t {
     FAST_MUL_SPECTRUM = 3  // [NumberValue(c), SpectrumValue(wavelength), Binary Mul]  == c * spectrum
 };
 
+// How a colour program gets onto the spectral tape (kernels.hip "Spectral tape"; round 4: scenes WITH interpreter programs):
+//   DIRECT     a constant or a fast shape: the record names it, the replay looks its value up per wavelength;
+//   HIT_VALUE  no instruction depends on the wavelength (diamonds.lua's `mix(0, 0.2, fresnel(1.1))`): the interpreter runs it ONCE
+//              per hit, where the path is shaded, and the value is folded into the record's factor;
+//   HIT_RGB    everything but a closing RgbSpectrumValue(wavelength, rgb) is independent of the wavelength (a colour texture, an
+//              rgb() expression): the interpreter evaluates the rgb register once per hit, the record carries its three components
+//              and the replay forms rgb . RGB_basis(wavelength) per wavelength, the very sum execution_context.rs:140-152 forms;
+//   NONE       needs an interpreter run per wavelength (a blackbody, a mix of spectra by a fresnel term, ...): a scene with such a
+//              COLOUR program keeps the online form of round 3 (Walker::contribute_pending).
+enum TapeForm : uint32_t { TAPE_FORM_DIRECT = 0, TAPE_FORM_HIT_VALUE = 1, TAPE_FORM_HIT_RGB = 2, TAPE_FORM_NONE = 3 };
+
 struct DevProgram {
     uint32_t kind; // PyrProgramKind
     float constant;
@@ -71,6 +82,8 @@ struct DevProgram {
     uint32_t fast_spectrum;   // spectrum id of the fast forms
     float fast_scale;         // c of the fast forms
     uint32_t reads_wavelength; // some executed operand is Input(Wavelength): ProbabilityInput::wavelength_used
+    uint32_t tape_form;        // TapeForm
+    uint32_t tape_rgb_reg;     // HIT_RGB: the rgb register the closing RgbSpectrumValue reads
 };
 
 struct DevScene {
@@ -114,6 +127,10 @@ struct DevScene {
     // some emissive component's probability program reads the wavelength: a light sample of such a material is added for the hero
     // wavelength only (algorithm.rs:78), i.e. the spectral tape can hold hero-only records. No BASELINE scene has one.
     uint32_t hero_only_records;
+    // needs_interpreter != 0 and every colour program (components, lamps, sky) has a tape form: the stage scheduler records a tape
+    // for this scene too and the interpreter runs once per hit instead of once per hit and wavelength
+    uint32_t hit_tape;
+    uint32_t rgb_records; // some colour program is HIT_RGB: its contributions are four records (three coefficients + the factor)
 };
 
 constexpr uint32_t kMaxStackDepth = 64; // >= kMaxBvhDepth (bvh.h) and >= the wide tree's stack need (else the binary tree is walked)
@@ -191,7 +208,8 @@ int launch_assemble(const AssembleLaunch& launch, void* stream);
 
 // launchers (kernels.hip)
 int launch_render(const DevScene& scene, const RenderLaunch& launch, bool with_counters, void* stream, int num_cus);
-uint32_t tape_ops_bound(const RenderLaunch& launch); // records per path the stage-scheduled kernel may append to its spectral tape
+uint32_t tape_ops_bound(const DevScene& scene, const RenderLaunch& launch); // records per path the stage-scheduled kernel may append to its spectral tape
+bool uses_hit_tape(const DevScene& scene, const RenderLaunch& launch); // an interpreter scene that records a tape in this launch
 uint32_t tape_lanes_bound(int num_cus);              // lanes (tape columns) of the largest grid launch_render starts
 int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool with_counters, void* stream);
 const char* kernels_last_error();

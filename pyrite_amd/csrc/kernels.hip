@@ -329,6 +329,22 @@ DEV void texture_get(const DevScene& S, uint32_t id, float px, float py, float o
     ys[2] = ys[1] == h - 1 ? 0 : ys[1] + 1;
     ys[3] = ys[2] == h - 1 ? 0 : ys[2] + 1;
     const float fx = x - x_floor, fy = y - y_floor;
+    if (t.channels == 4 && (t.offset & 3ull) == 0ull) {
+        // a colour texture whose texels are 16-byte aligned: the sixteen texels as sixteen dwordx4 loads instead of sixty-four dword
+        // loads, row by row; per channel the same cubic_interpolate calls on the same values as the loop below
+        const float4* texels = reinterpret_cast<const float4*>(data);
+        float rows[4][4];
+        for (int r = 0; r < 4; ++r) {
+            const float4* row = texels + (size_t)ys[r] * t.width;
+            const float4 a = row[xs[0]], b = row[xs[1]], c = row[xs[2]], d = row[xs[3]];
+            rows[r][0] = cubic_interpolate(a.x, b.x, c.x, d.x, fx);
+            rows[r][1] = cubic_interpolate(a.y, b.y, c.y, d.y, fx);
+            rows[r][2] = cubic_interpolate(a.z, b.z, c.z, d.z, fx);
+            rows[r][3] = cubic_interpolate(a.w, b.w, c.w, d.w, fx);
+        }
+        for (int ch = 0; ch < 4; ++ch) out[ch] = cubic_interpolate(rows[0][ch], rows[1][ch], rows[2][ch], rows[3][ch], fy);
+        return;
+    }
     for (uint32_t ch = 0; ch < t.channels; ++ch) {
         float rows[4];
         for (int r = 0; r < 4; ++r) {
@@ -2223,6 +2239,10 @@ constexpr uint32_t TAPE_MUL = 0u, TAPE_ADD = 1u, TAPE_SCALE = 2u, TAPE_HERO_ONLY
 // plain factor: both name the slot that holds 1.0 (x * 1.0 is x, bit for bit), so the replay has one straight-line form.
 constexpr uint32_t TAPE_EAGER_ADD = 1u << 31, TAPE_EAGER_SLOT_SHIFT = 8, TAPE_EAGER_SLOT_MASK = 0xFu << TAPE_EAGER_SLOT_SHIFT;
 constexpr uint32_t kTapeOneSlot = kTapeEagerSlots - 1; // the value row that holds 1.0
+// Eager records of a HIT_RGB contribution (device_scene.h TapeForm; scenes with S.rgb_records): bits 12-13 of the word say what the
+// record does with m = value[slot] * s -- 1: t = m (first coefficient times the red basis), 2: t = t + m (green, blue),
+// 3: m = t * s, then applied like any record (the contribution's factor). 0: an ordinary record.
+constexpr uint32_t TAPE_RGB_SHIFT = 12, TAPE_RGB_FIRST = 1u << TAPE_RGB_SHIFT, TAPE_RGB_NEXT = 2u << TAPE_RGB_SHIFT, TAPE_RGB_APPLY = 3u << TAPE_RGB_SHIFT;
 static_assert(BLOCK == 1u << TAPE_EAGER_SLOT_SHIFT, "an eager record's slot field is an index into rows of BLOCK floats");
 
 // Where record `op` of tape column `column` lives: [op][column], a row of one record index is contiguous (512 B per wave).
@@ -2268,6 +2288,15 @@ struct Walker {
 #endif
         n_ops++;
     }
+    // One eager record as it stands (HIT_VALUE / HIT_RGB contributions: Walker::tape_pending).
+    DEV void tape_push_raw(const RenderLaunch& L, uint32_t word, float s) {
+        if (n_ops < L.tape_max_ops)
+            L.tape[tape_index(n_ops, L.tape_lanes, tape_column)] = (unsigned long long)word | ((unsigned long long)__float_as_uint(s) << 32);
+        else
+            *L.tape_overflow = 1u;
+        n_ops++;
+    }
+    uint32_t rgb_slot = 0; // eager replay of a scene with HIT_RGB programs: the value slot of the red basis (green and blue follow)
     uint32_t chunk = 0; // next chunk of this lane's sample sequence (chunk_begin + wave, + total_waves, ...)
     Path p{};
     Trav t{};
@@ -2358,12 +2387,70 @@ struct Walker {
         }
     }
 
+    // Interpreter builds WITH a tape (scenes whose colour programs all have a tape form, device_scene.h TapeForm; round 4): what the
+    // phase noted is not applied wavelength by wavelength here, at the width of a SHADE / NEE phase -- that was 60 % of such a
+    // scene's wave cycles (profiles/r04_phase_profile_interpreter.txt) -- it is RECORDED: the interpreter runs what depends on the
+    // hit alone, once (the probability program at the hero wavelength, ProbabilityInput; a HIT_VALUE colour program whole; the rgb
+    // register of a HIT_RGB one), and the replay (replay_tapes) does the per-wavelength part for one (path, wavelength) pair per
+    // lane. The products are the ones contribute forms: value * (outer * (probability * compensation)), then the BRDF factor.
+    DEV void tape_pending(const DevScene& S, const RenderLaunch& L) {
+        if constexpr (INTERP && TAPE) {
+            if (c_kind != CONTRIB_NONE) {
+                VmInput in{p.wl, c_normal, c_incident, c_tx, c_ty};
+                Vm vm;
+                float cp = c_cp, hit_value = 1.0f;
+                const DevProgram colour = S.programs[c_color];
+                const bool run_colour = colour.kind != PYR_PROGRAM_CONSTANT && colour.fast == FAST_NONE; // HIT_VALUE or HIT_RGB: the interpreter runs its hit part
+                // job 0: the probability program in full (it is evaluated for the hero wavelength only); job 1: the colour program's
+                // instructions that do not depend on the wavelength -- all of a HIT_VALUE program, all but the closing one of a HIT_RGB
+                for (uint32_t job = c_probability >= 0 ? 0u : 1u; job < 2u; ++job) {
+                    if (job == 1u && !run_colour) break;
+                    const uint32_t id = job == 0u ? (uint32_t)c_probability : c_color;
+                    const DevProgram prog = S.programs[id];
+                    const bool interpreted = prog.kind != PYR_PROGRAM_CONSTANT && prog.fast == FAST_NONE;
+                    float v;
+                    if (interpreted) {
+                        const uint32_t count = (job == 1u && prog.tape_form == TAPE_FORM_HIT_RGB) ? prog.num_instrs - 1u : prog.num_instrs;
+                        for (uint32_t k = 0; k < count; ++k) vm.step(S, S.instrs[prog.first_instr + k], in);
+                        v = vm.number(prog);
+                    } else {
+                        const Prepared q = prepare_program<false>(S, id);
+                        v = eval_prepared<false>(S, q, in);
+                    }
+                    if (job == 0u)
+                        cp = v * c_cp;
+                    else
+                        hit_value = v;
+                }
+                const float factor = c_use_outer ? c_outer * cp : cp;
+                const uint32_t flags = (c_kind == CONTRIB_ADD ? TAPE_EAGER_ADD : 0u) | (c_companions ? 0u : TAPE_HERO_ONLY);
+                if (!run_colour) {
+                    tape_push(L, c_kind == CONTRIB_ADD ? TAPE_ADD : TAPE_MUL, c_color, factor, !c_companions);
+                } else if (colour.tape_form == TAPE_FORM_HIT_VALUE) {
+                    tape_push_raw(L, flags | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), hit_value * factor); // value * factor is the product contribute forms
+                } else { // HIT_RGB: c0 * basis_r + c1 * basis_g + c2 * basis_b (execution_context.rs:140-152), then times the factor
+                    const float* c = vm.rgb[colour.tape_rgb_reg & (PYR_MAX_VECTOR_REGISTERS - 1)];
+                    const uint32_t hero = c_companions ? 0u : TAPE_HERO_ONLY;
+                    tape_push_raw(L, hero | TAPE_RGB_FIRST | ((rgb_slot + 0u) << TAPE_EAGER_SLOT_SHIFT), c[0]);
+                    tape_push_raw(L, hero | TAPE_RGB_NEXT | ((rgb_slot + 1u) << TAPE_EAGER_SLOT_SHIFT), c[1]);
+                    tape_push_raw(L, hero | TAPE_RGB_NEXT | ((rgb_slot + 2u) << TAPE_EAGER_SLOT_SHIFT), c[2]);
+                    tape_push_raw(L, flags | TAPE_RGB_APPLY | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), factor);
+                }
+                c_kind = CONTRIB_NONE;
+            }
+            if (c_has_scale) {
+                tape_push(L, TAPE_SCALE, 0u, c_scale);
+                c_has_scale = false;
+            }
+        }
+    }
+
     // tracer.rs:288-301 tail of a bounce + loop head :221: reflectance *= brdf, next ray, bounce count
     DEV void finish_bounce(const DevScene& S, const RenderLaunch& L, Spectral& spec, Counters& cnt) {
         const uint32_t n_add = L.spectrum_samples - 1;
         if (b_has_brdf) {
             const float brdf = 2.0f * fabsf(dot(b_out, b_normal));
-            if constexpr (TAPE) {
+            if constexpr (TAPE && !INTERP) {
                 tape_push(L, TAPE_SCALE, 0u, brdf);
             } else if constexpr (INTERP) {
                 c_scale = brdf, c_has_scale = true; // behind this turn's contribution (contribute_pending)
@@ -2431,7 +2518,7 @@ struct Walker {
                     }
                 }
             }
-            if constexpr (TAPE) {
+            if constexpr (TAPE && !INTERP) {
                 tape_push(L, TAPE_ADD, color, 1.0f);
             } else if constexpr (INTERP) {
                 contribution(CONTRIB_ADD, color, -1, 1.0f, false, 1.0f, p.use_additional, -ray_d, ray_d, 0.0f, 0.0f);
@@ -2464,7 +2551,7 @@ struct Walker {
         bool normal_dispersed = false;
         int deferred_probability = -1; // interpreter builds evaluate it with the colour program (contribute_pending)
         if (comp.probability_program >= 0) {
-            if constexpr (INTERP && !TAPE) {
+            if constexpr (INTERP) {
                 deferred_probability = comp.probability_program;
             } else {
                 VmInput pin{p.wl, normal, ray_d, tx, ty};
@@ -2475,7 +2562,7 @@ struct Walker {
         if (comp.bsdf == PYR_BSDF_EMISSIVE) {
             if (p.sample_light) {
                 p.use_additional = !normal_dispersed && p.use_additional;
-                if constexpr (TAPE) {
+                if constexpr (TAPE && !INTERP) {
                     tape_push(L, TAPE_ADD, comp.color_program, component_probability);
                 } else if constexpr (INTERP) {
                     contribution(CONTRIB_ADD, comp.color_program, deferred_probability, comp.selection_compensation, false, 1.0f, p.use_additional, normal, ray_d, tx, ty);
@@ -2516,7 +2603,7 @@ struct Walker {
         }
         const float bounce_probability = scatter_probability * component_probability;
         p.use_additional = !(dispersed || normal_dispersed) && p.use_additional;
-        if constexpr (TAPE) {
+        if constexpr (TAPE && !INTERP) {
             tape_push(L, TAPE_MUL, comp.color_program, bounce_probability);
         } else if constexpr (INTERP) {
             // bounce_probability = scatter_probability * (probability program's value * compensation), formed where the value is
@@ -2577,7 +2664,7 @@ struct Walker {
                     const PyrComponent ec = S.components[lm.first_emissive + e_pick];
                     material_probability = ec.selection_compensation;
                     if (ec.probability_program >= 0) {
-                        if constexpr (INTERP && !TAPE) {
+                        if constexpr (INTERP) {
                             deferred_probability = ec.probability_program;
                         } else {
                             VmInput pin{p.wl, ls_normal, t.d, ls_tx, ls_ty};
@@ -2589,7 +2676,7 @@ struct Walker {
                     target_normal = ls_normal;
                 }
                 const float l_probability = ls_scale * material_probability;
-                if constexpr (TAPE) {
+                if constexpr (TAPE && !INTERP) {
                     tape_push(L, TAPE_ADD, l_color, l_probability, l_dispersed);
                 } else if constexpr (INTERP) {
                     // l_probability = ls_scale * (probability program's value * compensation); the material's inputs are the light's
@@ -2638,7 +2725,7 @@ struct Walker {
 // synchronous walk. Must be called by every lane of the wave.
 template <bool COUNT>
 DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wl_rows,
-                      uint32_t wl_column, uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, Counters& cnt) {
+                      uint32_t wl_column, uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, bool eager, Counters& cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = ballot64(exposing);
     const uint32_t n = (uint32_t)__popcll(mask);
@@ -2675,9 +2762,8 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
     // of dependent HBM round trips: it took a quarter of the render.) Lanes that are not being replayed load nothing.
     // Rows past the end of a tape read as the identity record of the eager form -- "reflectance *= value[one] * 1.0", and
     // x * 1.0 is x bit for bit -- so the straight-line replay needs no "is this row still on my tape" test per record.
-    const bool eager_form = n_spectral != 0;
     const unsigned long long past_the_end =
-        eager_form ? ((unsigned long long)(kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT) | ((unsigned long long)__float_as_uint(1.0f) << 32)) : 0ull;
+        eager ? ((unsigned long long)(kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT) | ((unsigned long long)__float_as_uint(1.0f) << 32)) : 0ull;
 #ifndef PYR_REPLAY_ROWS
 #define PYR_REPLAY_ROWS 8
 #endif
@@ -2705,7 +2791,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         // A scene has few programs that read a spectrum (C3: three wall colours and the lamp). When they fit the LDS rows
         // reserved for them, each is looked up once per item, here, in uniform control flow -- the records below then only pick
         // the value (and apply the program's constant factor, the same multiplication run_program makes).
-        const bool eager = n_spectral != 0;
+        float rgb_sum = 0.0f; // HIT_RGB contributions: c0 * basis_r + c1 * basis_g + c2 * basis_b in the making
         if (eager) {
             // Spectrum::get (project/spectra.rs:32-55) of every slot at this item's wavelength, the operations of spectrum_eval.
             // Array spectra over the same grid (min, max, count: C3's three wall colours) share the index arithmetic -- one
@@ -2746,6 +2832,26 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 #endif
                 spectral_values[slot * BLOCK] = mode == FAST_SPECTRUM ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
             }
+            if (S.rgb_records != 0) { // (uniform) the RGB basis at this item's wavelength: RgbSpectrumValue's look-up, execution_context.rs:140-152
+                float resp[3] = {0.0f, 0.0f, 0.0f};
+                const uint32_t count = S.rgb_count;
+                if (count > 0) {
+                    const float* d = S.rgb_basis;
+                    if (wl <= S.rgb_min) {
+                        for (int j = 0; j < 3; ++j) resp[j] = d[j];
+                    } else if (wl >= S.rgb_max) {
+                        for (int j = 0; j < 3; ++j) resp[j] = d[3 * (count - 1) + j];
+                    } else {
+                        const float normalized = (wl - S.rgb_min) / (S.rgb_max - S.rgb_min);
+                        const float fi = normalized * ((float)count - 1.0f);
+                        const float fmin_ = truncf(fi);
+                        const uint32_t b0 = (uint32_t)fmin_;
+                        const float bmix = fi - fmin_;
+                        for (int j = 0; j < 3; ++j) resp[j] = d[3 * b0 + j] * (1.0f - bmix) + d[3 * (b0 + 1) + j] * bmix;
+                    }
+                }
+                for (uint32_t j = 0; j < 3; ++j) spectral_values[(n_spectral + j) * BLOCK] = resp[j];
+            }
         }
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
             unsigned long long rows[ROWS];
@@ -2763,6 +2869,22 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 float values[ROWS];
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) values[j] = spectral_values[words[j] & TAPE_EAGER_SLOT_MASK]; // slot << 8 is slot * BLOCK
+                if (S.rgb_records != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it
+                    const uint32_t not_mine = hero ? 0u : TAPE_HERO_ONLY;
+#pragma unroll
+                    for (uint32_t j = 0; j < ROWS; ++j) {
+                        const float m = values[j] * factors[j];
+                        const uint32_t op = (words[j] >> TAPE_RGB_SHIFT) & 3u;
+                        rgb_sum = op == 1u ? m : (op == 2u ? rgb_sum + m : rgb_sum);
+                        const float mm = op == 3u ? rgb_sum * factors[j] : m;
+                        const bool apply = ((words[j] & not_mine) == 0u) & ((op == 0u) | (op == 3u));
+                        const bool adds = (int)words[j] < 0;
+                        const float multiplied = refl * mm, added = bright + multiplied;
+                        bright = (apply & adds) ? added : bright;
+                        refl = (apply & !adds) ? multiplied : refl;
+                    }
+                    continue;
+                }
                 if (S.hero_only_records == 0) { // (uniform) no record of this scene is for the hero alone: every record applies
 #pragma unroll
                     for (uint32_t j = 0; j < ROWS; ++j) {
@@ -2843,7 +2965,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 // program's value among the programs that read a spectrum), followed by the slot -> program list. Returns the number of
 // spectrum-reading programs when they fit the kTapeEagerSlots value rows (the replay then looks each up once per item), else
 // 0 (looked up record by record). Called by every thread of the workgroup; ends with a barrier.
-DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const RenderLaunch& L, uint32_t* prepared_lds) {
+DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const RenderLaunch& L, uint32_t* prepared_lds, bool& eager) {
     // Programs that evaluate alike -- the same shape, factor and spectrum (a scene compiles one colour program per use: C3's
     // three white walls are three programs over one spectrum) -- share a value slot: the replay looks a slot up once per item.
     auto reads_spectrum = [&](uint32_t i) { return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && S0.programs[i].fast != FAST_NONE; };
@@ -2874,7 +2996,13 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
         if (spectral && representative == i && slot < kTapeOneSlot) prepared_lds[8 * L.tape_programs_lds + slot] = i;
     }
     __syncthreads();
-    return n_spectral > kTapeOneSlot ? 0u : n_spectral; // too many for the reserved rows (the last one holds 1.0): the replay looks them up record by record
+    // The value rows (the last one holds 1.0; a scene with HIT_RGB programs keeps the RGB basis in three of them, behind the
+    // programs' slots): too many spectrum-reading programs for them and the replay looks values up record by record. A scene
+    // without any such program has nothing to look up eagerly -- unless it records hit-tape forms, which only the eager replay knows
+    // (api.cpp makes sure they fit).
+    const uint32_t needed = n_spectral + (S0.rgb_records != 0 ? 3u : 0u);
+    eager = L.tape_programs_lds != 0 && needed <= kTapeOneSlot && (n_spectral != 0 || S0.hit_tape != 0);
+    return eager ? n_spectral : 0u;
 }
 
 // Interpreter builds keep the program interpreter in line (Walker::contribute_pending): register files, a bicubic texture
@@ -2884,10 +3012,14 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
 #ifndef PYR_SM_WAVES_INTERP
 #define PYR_SM_WAVES_INTERP 2
 #endif
-template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES>
-__global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
+#ifndef PYR_SM_WAVES_HIT_TAPE
+#define PYR_SM_WAVES_HIT_TAPE 2 // interpreter builds that record a tape (HIT_TAPE)
+#endif
+template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES, bool HIT_TAPE = false>
+__global__ __launch_bounds__(BLOCK, INTERP ? (HIT_TAPE ? PYR_SM_WAVES_HIT_TAPE : PYR_SM_WAVES_INTERP) : PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
-    constexpr bool TAPE = !INTERP; // see "Spectral tape"
+    static_assert(INTERP || !HIT_TAPE, "HIT_TAPE is a form of the interpreter build");
+    constexpr bool TAPE = !INTERP || HIT_TAPE; // see "Spectral tape"; interpreter builds: scenes whose colour programs all have a tape form
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
     // LDS rows of 256 floats: TAPE: S wavelengths + one row of per-wave lane lists; else wavelengths / brightness / reflectance
@@ -2915,15 +3047,18 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
     uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_SCENE ? (S0.num_nodes * 16 + S0.num_prims * 12) : 0) + (LDS_TABLES ? S0.lds_table_floats : 0));
     // programs that read a spectrum get a slot (their rank among such programs); the slot -> program list follows the table
     uint32_t n_spectral = 0;
+    bool eager = false;
     float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
     if constexpr (TAPE) {
         // eager records of constant programs and BRDF factors (tape_push). TAPE builds only: without the tape these rows are not
         // reserved, and with few wavelengths the store landed in the staged scene (found by the fuzz campaign of round 3: two
         // wavelengths, a tree four levels deep -- row SS + 8 was the first KB of the LDS copy of the nodes)
         spectral_values[kTapeOneSlot * BLOCK] = 1.0f;
-        n_spectral = prepare_tape_tables(S0, S, L, prepared_lds);
-        if (n_spectral != 0) w.tape_prepared = prepared_lds;
+        n_spectral = prepare_tape_tables(S0, S, L, prepared_lds, eager);
+        if (eager) w.tape_prepared = prepared_lds;
+        w.rgb_slot = n_spectral;
         w.tape_column = blockIdx.x * BLOCK + threadIdx.x;
+        if (HIT_TAPE && !eager) *L.tape_overflow = 1u; // api.cpp only marks a scene hit_tape when its value slots fit: never taken
     }
 
     // the scene record as the phases see it (table pointers at the staged copies), rebuilt where a phase starts
@@ -2947,7 +3082,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             const RenderLaunch& Lp = launch_from_kernarg(L);
             const DevScene Sp = scene_view(Lp);
-            if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+            if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral, eager, cnt);
             w.expose_and_restart(Sp, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(ballot64(w.stage == ST_TRAV));
@@ -2976,9 +3111,17 @@ __global__ __launch_bounds__(BLOCK, INTERP ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
             nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
         }
         if constexpr (INTERP) { // what SHADE / NEE of this turn noted for `contribute`: one in-line interpreter (Walker::contribute_pending)
-            if (ballot64(w.c_kind != 0u || w.c_has_scale) != 0ull) {
+            const unsigned long long pending = ballot64(w.c_kind != 0u || w.c_has_scale);
+            if (pending != 0ull) {
+                [[maybe_unused]] const unsigned long long t_c0 = PROF_NOW();
+                PROF_EXTRA(13, __popcll(pending));
+                PROF_EXTRA(14, 1);
                 const RenderLaunch& Lp = launch_from_kernarg(L);
-                w.contribute_pending(scene_view(Lp), Lp, spec);
+                if constexpr (HIT_TAPE)
+                    w.tape_pending(scene_view(Lp), Lp);
+                else
+                    w.contribute_pending(scene_view(Lp), Lp, spec);
+                PROF_EXTRA(12, PROF_NOW() - t_c0);
             }
         }
         // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
@@ -3173,13 +3316,14 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_px(DevScene
     lds_u32* to_logic = px + kPxQueueWords;
     lds_u32* control = px + 2 * kPxQueueWords; // [0] homes whose sequence has not ended, [1] next home to start, [2] give up
     for (uint32_t i = threadIdx.x; i < kPxLdsWords; i += BLOCK) px[i] = i == 2 * kPxQueueWords ? (uint32_t)BLOCK : 0u; // control[0]: every home is alive
-    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds); // ends with a barrier: the queues are clear behind it
+    bool eager = false;
+    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds, eager); // ends with a barrier: the queues are clear behind it
     // two of the four waves walk the tree; which two alternates with the workgroup's round on its CU, so that a SIMD -- wave w of
     // every resident workgroup -- gets both kinds of wave
     const bool trav_role = ((wave + (blockIdx.x >> 8)) & 1u) == 0u;
     Walker<COUNT, false, true> w;
     w.stage = ST_VACANT;
-    w.tape_prepared = n_spectral != 0 ? prepared_lds : nullptr;
+    w.tape_prepared = eager ? prepared_lds : nullptr;
     uint32_t home = 0;
     uint32_t idle_turns = 0, starved_turns = 0;
     auto scene_view = [&](const RenderLaunch& Lp) {
@@ -3296,7 +3440,7 @@ __global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_px(DevScene
                 PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
                 const RenderLaunch& Lp = launch_from_kernarg(L);
                 const DevScene Sp = scene_view(Lp);
-                replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, home, wave_list, prepared_lds, spectral_values, n_spectral, cnt);
+                replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, home, wave_list, prepared_lds, spectral_values, n_spectral, eager, cnt);
                 const bool was_live = w.stage == ST_EXPOSE || w.stage == ST_NEW;
                 w.expose_and_restart(Sp, Lp, spec, cnt, home & 63u, total_waves);
                 const unsigned long long ended = ballot64(was_live && w.stage == ST_DONE);
@@ -3634,11 +3778,19 @@ static uint32_t short_stack_levels(const DevScene& scene, size_t other_bytes, ui
 }
 // Records a path can append: one MUL and one SCALE per bounce, light_samples ADDs in each of the two next-event estimations
 // (tracer.rs:257), one closing ADD (emission or sky).
-uint32_t tape_ops_bound(const RenderLaunch& launch) { return 2u * launch.bounces + 2u * launch.light_samples + 1u; }
+// A contribution whose colour program is HIT_RGB is four records (three coefficients and the factor).
+uint32_t tape_ops_bound(const DevScene& scene, const RenderLaunch& launch) {
+    return (launch.bounces + 2u * launch.light_samples + 1u) * (scene.rgb_records ? 4u : 1u) + launch.bounces;
+}
 uint32_t tape_lanes_bound(int num_cus) { return (uint32_t)num_cus * 8u * BLOCK; } // launch_render never starts more than 8 blocks per CU
 constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for the replay (4 KB); scenes with more use the HBM records
 static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_programs <= kTapeProgramsLds ? scene.num_programs : 0u; }
-static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) { return (launch.scheduler == 1 || launch.scheduler == 2) && scene.needs_interpreter == 0; }
+// Interpreter scenes record a tape when their colour programs allow it (DevScene::hit_tape) and there are wavelengths to share a
+// hit's work among: with one or two per sample the online form wins (diamonds.lua, one wavelength, 256 bounces: 538 against 486).
+bool uses_hit_tape(const DevScene& scene, const RenderLaunch& launch) { return scene.needs_interpreter != 0 && scene.hit_tape != 0 && launch.spectrum_samples >= 4; }
+static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) {
+    return (launch.scheduler == 1 || launch.scheduler == 2) && (scene.needs_interpreter == 0 || uses_hit_tape(scene, launch));
+}
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
     size_t bytes = (spectral_rows + launch.stack_lds) * BLOCK * sizeof(float);
@@ -3651,7 +3803,7 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
 
 using RenderKernel = void (*)(DevScene, RenderLaunch);
 template <bool C, bool I, bool L>
-static RenderKernel pick_tables(bool sm, bool lds_tables) {
+static RenderKernel pick_tables(bool sm, bool lds_tables, bool hit_tape) {
 #ifdef PYR_DEV_ONLY_SM // developer builds for reading the ISA (tools/asm_sm.sh): only the kernel the BASELINE meshes run is instantiated
     return render_kernel_sm<false, false, false, true>;
 #endif
@@ -3660,16 +3812,19 @@ static RenderKernel pick_tables(bool sm, bool lds_tables) {
 #endif
     // the synchronous walk is built without the interpreter only: a scene with interpreter programs runs on the stage scheduler,
     // which keeps the interpreter in line (api.cpp render_batches routes it there; this keeps the out-of-line builds out of the library)
+    if constexpr (I) {
+        if (hit_tape) return lds_tables ? render_kernel_sm<C, true, L, true, true> : render_kernel_sm<C, true, L, false, true>;
+    }
     if (sm || I) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
     return lds_tables ? render_kernel<C, false, L, true> : render_kernel<C, false, L, false>;
 }
 template <bool C, bool I>
-static RenderKernel pick_scene(bool sm, bool lds_scene, bool lds_tables) {
-    return lds_scene ? pick_tables<C, I, true>(sm, lds_tables) : pick_tables<C, I, false>(sm, lds_tables);
+static RenderKernel pick_scene(bool sm, bool lds_scene, bool lds_tables, bool hit_tape) {
+    return lds_scene ? pick_tables<C, I, true>(sm, lds_tables, hit_tape) : pick_tables<C, I, false>(sm, lds_tables, hit_tape);
 }
-static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables) {
-    if (with_counters) return interp ? pick_scene<true, true>(sm, lds_scene, lds_tables) : pick_scene<true, false>(sm, lds_scene, lds_tables);
-    return interp ? pick_scene<false, true>(sm, lds_scene, lds_tables) : pick_scene<false, false>(sm, lds_scene, lds_tables);
+static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables, bool hit_tape) {
+    if (with_counters) return interp ? pick_scene<true, true>(sm, lds_scene, lds_tables, hit_tape) : pick_scene<true, false>(sm, lds_scene, lds_tables, false);
+    return interp ? pick_scene<false, true>(sm, lds_scene, lds_tables, hit_tape) : pick_scene<false, false>(sm, lds_scene, lds_tables, false);
 }
 
 bool scene_is_lds_resident(const DevScene& scene) { return scene_fits_lds(scene); }
@@ -3687,7 +3842,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     // runs on the stage scheduler
     if (launch.scheduler == 2 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene))) launch.scheduler = 1;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
-    launch.stack_lds = launch.scheduler != 0 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES)
+    launch.stack_lds = launch.scheduler != 0 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? (uses_hit_tape(scene, launch) ? PYR_SM_WAVES_HIT_TAPE : PYR_SM_WAVES_INTERP) : PYR_SM_WAVES)
                                              : scene.stack_depth;
     // a scene staged in LDS is a few dozen nodes: its whole stack is kept in LDS (the kernels built for such scenes have no
     // scratch part: TravStack::deep is one entry), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below applies
@@ -3699,7 +3854,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     }
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
-    RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0);
+    RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0,
+                                      launch.scheduler == 1 && uses_hit_tape(scene, launch));
     if (launch.scheduler == 2) {
         static const RenderKernel px_variants[2][2] = {{render_kernel_px<false, false>, render_kernel_px<false, true>}, {render_kernel_px<true, false>, render_kernel_px<true, true>}};
         kernel = px_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0];
@@ -3727,7 +3883,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     const uint32_t path_waves = BLOCK / 64; // waves of a workgroup that take chunks
     uint32_t blocks_needed = (chunks + path_waves - 1) / path_waves;
     if (grid > blocks_needed) grid = blocks_needed;
-    if (uses_tape(scene, launch) && (launch.tape == nullptr || (size_t)grid * BLOCK > launch.tape_lanes || launch.tape_max_ops < tape_ops_bound(launch))) {
+    if (uses_tape(scene, launch) && (launch.tape == nullptr || (size_t)grid * BLOCK > launch.tape_lanes || launch.tape_max_ops < tape_ops_bound(scene, launch))) {
         g_kernel_error = "the spectral tape is missing or too small for this launch";
         return PYR_ERR_INVALID_ARGUMENT;
     }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool: the reference's example scenes (interpreter programs) at their projects' own sizes, per scheduler.
-    python tools/bench_examples.py"""
+"""Developer tool: the reference's example scenes (interpreter programs) at their projects' own sizes: the default (the stage
+scheduler; with the hit tape of round 4 where the scene's colour programs allow it) and PYRITE_HIT_TAPE=0 (the online form of
+round 3).     python tools/bench_examples.py"""
 import os
 import sys
 import time
@@ -19,17 +20,15 @@ cases = {
     "textures 1024x512x400": scenes.textures_reference_example(os.path.join(ROOT, "tests", "golden", "textures"), 1024, 512, 400),
 }
 for name, project in cases.items():
+  for hit_tape in ("1", "0"):
+    os.environ["PYRITE_HIT_TAPE"] = hit_tape  # read when the scene is created
     world, cam, r, _ = scenes.build(project, seed=1)
     world.scene(0)
     W, H = project["image"]["width"], project["image"]["height"]
     film = torch.zeros((H, W, r.spectrum_bins, 2), dtype=torch.float32, device=dev)
     desc = abi.PyrFilmDesc(W, H, r.spectrum_bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
     stream = torch.cuda.current_stream(dev)
-    for sched in ("", "sync", "sm"):
-        if sched:
-            os.environ["PYRITE_SCHEDULER"] = sched
-        else:
-            os.environ.pop("PYRITE_SCHEDULER", None)
+    for sched in ("hit tape" if hit_tape == "1" else "online",):
         best = None
         try:
             for _ in range(3):
@@ -41,7 +40,7 @@ for name, project in cases.items():
                 torch.cuda.synchronize(dev)
                 ms = a.elapsed_time(b)
                 best = ms if best is None else min(best, ms)
-            print("%-36s %-8s %9.2f ms %8.1f Msamples/s" % (name, sched or "default", best, W * H * r.pixel_samples / best / 1e3), flush=True)
+            print("%-36s %-8s %9.2f ms %8.1f Msamples/s  weight %.6g" % (name, sched, best, W * H * r.pixel_samples / best / 1e3, float(film[..., 1].sum(dtype=torch.float64))), flush=True)
         except Exception as e:  # noqa: BLE001
-            print("%-36s %-8s failed: %s" % (name, sched or "default", e), flush=True)
+            print("%-36s %-8s failed: %s" % (name, sched, e), flush=True)
     world.close()

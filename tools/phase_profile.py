@@ -17,6 +17,10 @@ which = sys.argv[1] if len(sys.argv) > 1 else "C3"
 w, h, spp = (int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (480, 270, 32)
 if which == "C2":
     project = scenes.c2_cornell(w, h, spp)
+elif which == "TEX":  # the reference's textures project (interpreter programs, textures, normal maps)
+    project = scenes.textures_reference_example(os.path.join(ROOT, "tests", "golden", "textures"), w, h, spp)
+elif which == "SPHERES":
+    project = scenes.spheres_example(w, h, spp)
 elif which == "C5":
     project = scenes.c3_mesh_in_box(w, h, spp, glass=True, bounces=20)
 else:
@@ -50,7 +54,10 @@ for i, name in enumerate(["EXPOSE/NEW", "SHADE", "NEE", "TRAV"]):
     per_turn = cyc[i] / (n / (int(os.environ.get("PYRITE_SM_STEPS", "8")) if i == 3 else 1))
     print("%-11s %5.1f %% of wave cycles | mean active lanes %5.1f / 64 | %8.0f cycles per turn | %.2f turns per sample"
           % (name, 100.0 * cyc[i] / total, lanes[i] / n, per_turn, turns[i] * 64.0 / samples / (8 if i == 3 else 1)))
-if any(out[12:16]):  # render_kernel_px: waves in two roles
+if out[14] and not out[15]:  # interpreter builds: contribute_pending behind the phases
+    print("contribute (interpreter) %5.1f %% of wave cycles (not in the phases above) | mean lanes with something to apply %5.1f / 64 | %8.0f cycles per turn | %.2f turns per sample"
+          % (100.0 * out[12] / (total + out[12]), out[13] / float(out[14]), out[12] / float(out[14]), out[14] * 64.0 / samples))
+elif any(out[12:16]):  # render_kernel_px: waves in two roles
     logic, trav = float(max(out[14], 1)), float(max(out[15], 1))
     print("path exchange: traversal waves %.3g wave cycles: %.1f %% in traversal steps, %.1f %% exchanging paths, the rest waiting for work" % (trav, 100.0 * cyc[3] / trav, 100.0 * out[12] / trav))
     print("               logic waves     %.3g wave cycles: %.1f %% in EXPOSE / SHADE / NEE, %.1f %% exchanging paths, the rest waiting for work" % (logic, 100.0 * sum(cyc[0:3]) / logic, 100.0 * out[13] / logic))
