@@ -700,7 +700,10 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     if (L.scheduler == 0 && scene->dev.needs_interpreter != 0) L.scheduler = 1;
     const char* lanes = std::getenv("PYRITE_SM_LANES");
     const char* steps = std::getenv("PYRITE_SM_STEPS");
-    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : (L.scheduler == 2 ? 32u : 16u);
+    // lanes that make a phase run: 16 on the BASELINE meshes (swept in rounds 2 and 3); 32 where the phases are heavy and the rays
+    // short -- scenes that run the program interpreter (round 4, every example scene of the reference: textures 755 -> 859, spheres
+    // 887 -> 969, lamps 726 -> 812, diamonds 543 -> 564 Msamples/s; flat from 28 to 48) -- and for the path-exchange scheduler
+    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : (L.scheduler == 2 || scene->dev.needs_interpreter != 0 ? 32u : 16u);
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;

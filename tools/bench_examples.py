@@ -19,8 +19,11 @@ cases = {
     "lamps 384x256x256": scenes.lamps_example(384, 256, 256),
     "textures 1024x512x400": scenes.textures_reference_example(os.path.join(ROOT, "tests", "golden", "textures"), 1024, 512, 400),
 }
+only = os.environ.get("EXAMPLES")  # e.g. EXAMPLES=textures,spheres
 for name, project in cases.items():
-  for hit_tape in ("1", "0"):
+  if only and name.split()[0] not in only.split(","):
+      continue
+  for hit_tape in (os.environ.get("HIT_TAPE_MODES", "1,0").split(",")):
     os.environ["PYRITE_HIT_TAPE"] = hit_tape  # read when the scene is created
     world, cam, r, _ = scenes.build(project, seed=1)
     world.scene(0)
