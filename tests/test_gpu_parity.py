@@ -132,6 +132,37 @@ def test_all_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypat
         assert gcount[key] == ccount[key], key
 
 
+HIT_TAPE_CASES = {  # name: (project, does the scene record a tape when it may?)
+    "textures_reference_example": (lambda: scenes.textures_reference_example(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures"), 96, 48, 8), True),
+    "spheres_example": (CASES["spheres_example"], True),
+    "textures_example": (CASES["textures_example"], False),  # a mono texture times a spectrum: an interpreter run per wavelength
+    "lamps_example": (CASES["lamps_example"], False),        # a blackbody lamp: the same
+}
+
+
+@pytest.mark.parametrize("hit_tape", ["1", "0"])
+@pytest.mark.parametrize("name", sorted(HIT_TAPE_CASES))
+def test_interpreter_scenes_with_and_without_the_hit_tape(name, hit_tape, gpu_lib, monkeypatch):
+    """Round 4: a scene with interpreter programs whose colour programs all have a tape form (device_scene.h TapeForm: textures,
+    spheres; not lamps, whose blackbody lamp needs a run per wavelength) records a spectral tape -- the interpreter runs once per
+    hit, the replay does the per-wavelength part. PYRITE_HIT_TAPE=0 (read at scene creation) keeps round 3's online form. Both
+    are the oracle's film; and with the tape shrunk under its bound the hit-tape form -- and only it -- reports the overflow."""
+    from pyrite_amd._lib import PyriteGpuError
+
+    monkeypatch.setenv("PYRITE_HIT_TAPE", hit_tape)
+    project, eligible = HIT_TAPE_CASES[name]
+    gfilm, cfilm, gcount, ccount = render_both(project(), 11, gpu_lib)
+    assert_parity(gfilm, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+    monkeypatch.setenv("PYRITE_TEST_TAPE_OPS", "2")
+    if hit_tape == "1" and eligible:
+        with pytest.raises(PyriteGpuError, match="spectral tape"):
+            render_both(project(), 11, gpu_lib)
+    else:
+        render_both(project(), 11, gpu_lib)
+
+
 def test_ragged_image_and_odd_parameters(gpu_lib):
     project = scenes.c2_cornell(50, 37, 3)  # tiles of 16: ragged right column and bottom row
     project["renderer"] = renderer.simple(pixel_samples=3, tile_size=16, spectrum_samples=7, light_samples=1, bounces=3)

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$R/gpurun_out/tex
+OUT=${1:-$R/gpurun_out/tex}
 mkdir -p $OUT
 cd $R
 timeout -k 10 300 python3 -m pytest tests/test_reference_images.py -m gpu -x -q 2>&1 | tail -n 3
