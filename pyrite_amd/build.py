@@ -90,13 +90,40 @@ def build_host(force=False, verbose=False):
     return HOST_OUT
 
 
+def compile_library(out, extra_flags=(), verbose=False):
+    """The four sources -> objects in parallel -> one shared library. kernels.hip is compiled twice (-DPYR_TU=0: everything but
+    the interpreter builds of the stage scheduler; -DPYR_TU=1: only those, the heaviest kernels) so that the two halves build side
+    by side: 85 s -> ~50 s. -DPYR_PHASE_PROFILE builds keep one translation unit (their device-side counters are one variable)."""
+    import tempfile
+
+    flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    split = not any("PYR_PHASE_PROFILE" in f or "PYR_DEV_ONLY" in f for f in extra_flags)
+    units = [("kernels.hip", ["-DPYR_TU=0"]), ("kernels.hip", ["-DPYR_TU=1"])] if split else [("kernels.hip", [])]
+    units += [(src, []) for src in SOURCES if src != "kernels.hip"]
+    with tempfile.TemporaryDirectory(prefix="pyrite_build_") as tmp:
+        jobs = []
+        for k, (src, unit_flags) in enumerate(units):
+            obj = os.path.join(tmp, "%d_%s.o" % (k, os.path.splitext(src)[0]))
+            cmd = [HIPCC] + flags + unit_flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((subprocess.Popen(cmd, cwd=CSRC), cmd, obj))
+        objects = []
+        for proc, cmd, obj in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+            objects.append(obj)
+        link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objects + ["-ldl"]
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link, cwd=CSRC)
+    return out
+
+
 def build(force=False, extra_flags=(), verbose=False):
     build_images(force, verbose)
     if force or stale():
-        cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", OUT] + SOURCES + ["-ldl"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd, cwd=CSRC)
+        compile_library(OUT, extra_flags, verbose)
     build_host(force, verbose)
     return OUT
 
@@ -107,11 +134,7 @@ def build_variant(name, extra_flags, verbose=False):
     out_dir = os.path.join(CSRC, "variants")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "lib_%s.so" % name)
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out] + SOURCES + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    return out
+    return compile_library(out, extra_flags, verbose)
 
 
 if __name__ == "__main__":

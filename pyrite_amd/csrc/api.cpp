@@ -690,8 +690,6 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
         L.scheduler = 1;
     else if (e && std::string(e) == "sync")
         L.scheduler = 0;
-    else if (e && std::string(e) == "px") // path-exchange scheduler (kernels.hip render_kernel_px); falls back to sm where it cannot run
-        L.scheduler = 2;
     else // the synchronous walk for scenes that live in LDS -- unless they run interpreter programs: the stage scheduler keeps the
          // interpreter in line and memoised (spheres example 572 -> 737, lamps 549 -> 724 Msamples/s against the synchronous walk)
         L.scheduler = scene_is_lds_resident(scene->dev) && scene->dev.needs_interpreter == 0 ? 0u : 1u;
@@ -702,8 +700,8 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     const char* steps = std::getenv("PYRITE_SM_STEPS");
     // lanes that make a phase run: 16 on the BASELINE meshes (swept in rounds 2 and 3); 32 where the phases are heavy and the rays
     // short -- scenes that run the program interpreter (round 4, every example scene of the reference: textures 755 -> 859, spheres
-    // 887 -> 969, lamps 726 -> 812, diamonds 543 -> 564 Msamples/s; flat from 28 to 48) -- and for the path-exchange scheduler
-    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : (L.scheduler == 2 || scene->dev.needs_interpreter != 0 ? 32u : 16u);
+    // 887 -> 969, lamps 726 -> 812, diamonds 543 -> 564 Msamples/s; flat from 28 to 48)
+    L.sm_phase_lanes = lanes && *lanes ? (uint32_t)std::strtoul(lanes, nullptr, 10) : (scene->dev.needs_interpreter != 0 ? 32u : 16u);
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;

@@ -23,16 +23,27 @@
 #include <cstdint>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "device_scene.h"
 #include "exact_math.h"
 
+// This file is compiled twice and in parallel by pyrite_amd/build.py: -DPYR_TU=0 holds every kernel and launcher but the
+// interpreter builds of render_kernel_sm, -DPYR_TU=1 holds only those (the heaviest kernels to compile: 252-256 VGPRs, the
+// interpreter in line) behind pick_interp_kernel(). Without the macro (-1: tools that compile kernels.hip by themselves, and the
+// -DPYR_PHASE_PROFILE builds, whose device-side counters must live in one translation unit) everything is in one piece.
+#ifndef PYR_TU
+#define PYR_TU -1
+#endif
+
 namespace pyr {
 
+#if PYR_TU != 1
 namespace {
 thread_local std::string g_kernel_error;
 }
 const char* kernels_last_error() { return g_kernel_error.c_str(); }
+#endif
 
 #define DEV __device__ __forceinline__
 // The lanes for which p holds, as the mask the comparison produced (HIP's __ballot() goes through an integer and back: a
@@ -2723,7 +2734,7 @@ struct Walker {
 // exposes its hero only (simple.rs:133-139); a light sample whose material reads the wavelength is added for the hero only
 // (algorithm.rs:78). Consecutive records of one program (the light samples of one estimation) share one look-up, as in the
 // synchronous walk. Must be called by every lane of the wave.
-template <bool COUNT>
+template <bool COUNT, bool RGB = false> // RGB: the scene may hold HIT_RGB records (interpreter builds that record a tape)
 DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wl_rows,
                       uint32_t wl_column, uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, bool eager, Counters& cnt) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -2791,7 +2802,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
         // A scene has few programs that read a spectrum (C3: three wall colours and the lamp). When they fit the LDS rows
         // reserved for them, each is looked up once per item, here, in uniform control flow -- the records below then only pick
         // the value (and apply the program's constant factor, the same multiplication run_program makes).
-        float rgb_sum = 0.0f; // HIT_RGB contributions: c0 * basis_r + c1 * basis_g + c2 * basis_b in the making
+        [[maybe_unused]] float rgb_sum = 0.0f; // HIT_RGB contributions: c0 * basis_r + c1 * basis_g + c2 * basis_b in the making
         if (eager) {
             // Spectrum::get (project/spectra.rs:32-55) of every slot at this item's wavelength, the operations of spectrum_eval.
             // Array spectra over the same grid (min, max, count: C3's three wall colours) share the index arithmetic -- one
@@ -2832,7 +2843,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 #endif
                 spectral_values[slot * BLOCK] = mode == FAST_SPECTRUM ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
             }
-            if (S.rgb_records != 0) { // (uniform) the RGB basis at this item's wavelength: RgbSpectrumValue's look-up, execution_context.rs:140-152
+            if (RGB && S.rgb_records != 0) { // (uniform) the RGB basis at this item's wavelength: RgbSpectrumValue's look-up, execution_context.rs:140-152
                 float resp[3] = {0.0f, 0.0f, 0.0f};
                 const uint32_t count = S.rgb_count;
                 if (count > 0) {
@@ -2869,7 +2880,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 float values[ROWS];
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) values[j] = spectral_values[words[j] & TAPE_EAGER_SLOT_MASK]; // slot << 8 is slot * BLOCK
-                if (S.rgb_records != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it
+                if (RGB && S.rgb_records != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it
                     const uint32_t not_mine = hero ? 0u : TAPE_HERO_ONLY;
 #pragma unroll
                     for (uint32_t j = 0; j < ROWS; ++j) {
@@ -3082,7 +3093,10 @@ __global__ __launch_bounds__(BLOCK, INTERP ? (HIT_TAPE ? PYR_SM_WAVES_HIT_TAPE :
             PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
             const RenderLaunch& Lp = launch_from_kernarg(L);
             const DevScene Sp = scene_view(Lp);
-            if constexpr (TAPE) replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral, eager, cnt);
+            // (without hit-tape forms the replay is eager exactly when it has value slots: one uniform less to keep across the loop)
+            if constexpr (TAPE)
+                replay_tapes<COUNT, HIT_TAPE>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral,
+                                              HIT_TAPE ? eager : n_spectral != 0, cnt);
             w.expose_and_restart(Sp, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
             nT = __popcll(ballot64(w.stage == ST_TRAV));
@@ -3150,339 +3164,11 @@ __global__ __launch_bounds__(BLOCK, INTERP ? (HIT_TAPE ? PYR_SM_WAVES_HIT_TAPE :
     flush_counters<COUNT>(cnt, L.counters);
 }
 
-// ------------------------------------------------------------------------------------------------ path-exchange scheduler
-// render_kernel_px (PYRITE_SCHEDULER=px): the stage-scheduled integrator with the PATHS of a
-// workgroup regrouped between its four waves. In render_kernel_sm a wave's 64 paths are spread over four stages and every
-// phase finds a fraction of the lanes (C3: traversal 33 / 64, SHADE 22, NEE 23). Here two waves of a workgroup only walk the
-// tree and two only run the logic phases (EXPOSE / SHADE / NEE), and a path moves to the other kind of wave whenever it changes
-// kind of work -- at a ray's start and at its end, when it has no traversal stack: 35 words through LDS. Unlike the split
-// scheduler of round 2 (which moved RAYS, kept the paths in the logic waves and so halved the paths in flight) every lane
-// of every wave is a seat that can hold a path: 256 paths per workgroup as before, the traversal seats all walking, the logic
-// seats all waiting for one of three pieces of logic.
-//   Homes. A path is the sample sequence of one of the workgroup's 256 "homes" (the lane numbers of render_kernel_sm): home h
-// walks chunks chunk_begin + 4 * block + h / 64, + total_waves, ... as lane h % 64, owns tape column 256 * block + h and the
-// LDS wavelength column h, whatever seat it sits in -- so every sample performs the operations of render_kernel_sm in the same
-// order and the films are identical.
-//   Queues. Two slot arrays in LDS (to the traversal waves / to the logic waves), kPxCap slots of a state word + kPxWords data
-// words each, [word][slot]. A lane with a path to hand over claims an EMPTY slot with a compare-and-swap (EMPTY -> WRITING),
-// writes the path, publishes it (FULL); a free seat of the other kind claims a FULL slot (-> READING), reads it, frees it
-// (EMPTY). Lanes probe slots (lane + 17 k) % kPxCap, so waves of one role do not fight over one slot. No order is kept: paths
-// are independent. LDS is in order per wave; release / acquire at workgroup scope keep the compiler honest.
-//   End. `live` counts homes whose sequence has not ended; every wave leaves when it reaches zero (no path exists then). No wave
-// waits for ever: idle turns are counted and past kPxSpinLimit the launch's error word is set (PYR_ERR_DEVICE).
-#ifndef PYR_PX_CAP
-#define PYR_PX_CAP 32
-#endif
-constexpr uint32_t kPxCap = PYR_PX_CAP, kPxWords = 35; // slots per queue: at most 64 (px_assign reads one slot's state per lane)
-constexpr uint32_t kPxQueueWords = kPxCap * (1 + kPxWords), kPxControlWords = 4;
-constexpr uint32_t kPxLdsWords = 2 * kPxQueueWords + kPxControlWords;
-constexpr uint32_t PX_EMPTY = 0u, PX_WRITING = 1u, PX_FULL = 2u, PX_READING = 3u;
-constexpr uint32_t ST_VACANT = 7u; // a seat without a path
-constexpr uint32_t kPxSpinLimit = 1u << 22;
-#ifndef PYR_PX_TRAV_STEPS
-#define PYR_PX_TRAV_STEPS 8
-#endif
-// Wave priorities of the two roles. NOT the stage scheduler's order: there every wave passes through every phase, here a role is
-// for life, and a logic wave at the bottom would be starved by the traversal waves it feeds.
-#ifndef PYR_PX_PRIO_T
-#define PYR_PX_PRIO_T 1
-#endif
-#ifndef PYR_PX_PRIO_E
-#define PYR_PX_PRIO_E 2
-#endif
-#ifndef PYR_PX_PRIO_S
-#define PYR_PX_PRIO_S 3
-#endif
-#ifndef PYR_PX_PRIO_N
-#define PYR_PX_PRIO_N 3
-#endif
-#ifndef PYR_PX_PATIENCE
-#define PYR_PX_PATIENCE 6 // turns a logic wave waits for a phase to reach its quorum before it runs the most wanted one with what it has
-#endif
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
-template <class W>
-DEV void px_store(const W& w, uint32_t home, lds_u32* data, uint32_t slot) {
-    uint32_t k = 0;
-    auto put = [&](uint32_t v) { data[(k++) * kPxCap + slot] = v; };
-    auto putf = [&](float v) { put(__float_as_uint(v)); };
-    put(w.p.rng.x), put(w.p.rng.y), put(w.p.rng.z), put(w.p.rng.w);
-    put(w.p.pixel), putf(w.p.wl), put(w.chunk);
-    put(home | (w.p.events << 8) | (w.p.use_additional ? 1u << 16 : 0u) | (w.p.sample_light ? 1u << 17 : 0u) | (w.b_flip ? 1u << 18 : 0u) | (w.b_has_brdf ? 1u << 19 : 0u) |
-        (w.ls_pending ? 1u << 20 : 0u) | (w.ls_physical ? 1u << 21 : 0u) | (w.t.shadow ? 1u << 22 : 0u) | (w.t.blocked ? 1u << 23 : 0u));
-    put(w.nee_i), put(w.nee_lamp), put(w.p.bounce), put(w.n_ops);
-    putf(w.t.o.x), putf(w.t.o.y), putf(w.t.o.z), putf(w.t.d.x), putf(w.t.d.y), putf(w.t.d.z), putf(w.t.limit);
-    putf(w.t.closest), put(w.t.shape), putf(w.t.u), putf(w.t.v);
-    putf(w.b_normal.x), putf(w.b_normal.y), putf(w.b_normal.z), putf(w.b_out.x), putf(w.b_out.y), putf(w.b_out.z);
-    putf(w.ls_normal.x), putf(w.ls_normal.y), putf(w.ls_normal.z), putf(w.ls_scale), put(w.ls_material), put(w.ls_color);
-    static_assert(kPxWords == 35, "px_store / px_load move kPxWords words");
-}
-template <class W>
-DEV uint32_t px_load(W& w, const lds_u32* data, uint32_t slot) { // returns the path's home
-    uint32_t k = 0;
-    auto get = [&]() { return data[(k++) * kPxCap + slot]; };
-    auto getf = [&]() { return __uint_as_float(get()); };
-    w.p.rng.x = get(), w.p.rng.y = get(), w.p.rng.z = get(), w.p.rng.w = get();
-    w.p.pixel = get(), w.p.wl = getf(), w.chunk = get();
-    const uint32_t flags = get();
-    w.p.events = (flags >> 8) & 0xffu;
-    w.p.use_additional = (flags >> 16) & 1u, w.p.sample_light = (flags >> 17) & 1u, w.b_flip = (flags >> 18) & 1u, w.b_has_brdf = (flags >> 19) & 1u;
-    w.ls_pending = (flags >> 20) & 1u, w.ls_physical = (flags >> 21) & 1u, w.t.shadow = (flags >> 22) & 1u, w.t.blocked = (flags >> 23) & 1u;
-    w.nee_i = get(), w.nee_lamp = get(), w.p.bounce = get(), w.n_ops = get();
-    w.t.o.x = getf(), w.t.o.y = getf(), w.t.o.z = getf(), w.t.d.x = getf(), w.t.d.y = getf(), w.t.d.z = getf(), w.t.limit = getf();
-    w.t.closest = getf(), w.t.shape = get(), w.t.u = getf(), w.t.v = getf();
-    w.b_normal.x = getf(), w.b_normal.y = getf(), w.b_normal.z = getf(), w.b_out.x = getf(), w.b_out.y = getf(), w.b_out.z = getf();
-    w.ls_normal.x = getf(), w.ls_normal.y = getf(), w.ls_normal.z = getf(), w.ls_scale = getf(), w.ls_material = get(), w.ls_color = get();
-    w.b_position = w.t.o; // the bounce's position IS the origin of the shadow ray in flight (trace_direct); dead otherwise
-    return flags & 0xffu;
-}
-// The k-th lane of the wave that `wants` a slot in state `needed` gets the k-th slot that is in it (as the wave saw the states a
-// moment ago): the slots' lanes put their numbers down in rank order in the wave's scratch row, the wanting lanes pick theirs
-// up. kPxCap for a lane that gets none. Must be called by every lane of the wave. (Lanes probing fixed slots of their own --
-// the first form of this scheduler -- left a quarter of the traversal seats holding paths that found no slot while as many
-// seats stood vacant: profiles/r04_phase_profile_px.txt.)
-DEV uint32_t px_assign(bool wants, uint32_t needed, const lds_u32* state, uint32_t* wave_scratch, uint32_t lane) {
-    const unsigned long long wanting = ballot64(wants);
-    if (wanting == 0ull) return kPxCap;
-    const uint32_t mine = lane < kPxCap ? __hip_atomic_load(state + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
-    const unsigned long long open = ballot64(mine == needed);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (mine == needed) wave_scratch[__popcll(open & below)] = lane;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t rank = (uint32_t)__popcll(wanting & below);
-    uint32_t slot = kPxCap;
-    if (wants && rank < (uint32_t)__popcll(open)) slot = wave_scratch[rank];
-    __builtin_amdgcn_wave_barrier();
-    return slot;
-}
-// Lanes that `want` to hand their path over: true for those whose path is in the queue now.
-template <class W>
-DEV bool px_push(bool wants, const W& w, uint32_t home, lds_u32* queue, uint32_t* wave_scratch, uint32_t lane) {
-    lds_u32* state = queue;
-    lds_u32* data = queue + kPxCap;
-    const uint32_t slot = px_assign(wants, PX_EMPTY, state, wave_scratch, lane);
-    bool sent = false;
-    if (slot < kPxCap) {
-        uint32_t expected = PX_EMPTY; // the other wave of this role may have taken it since
-        if (__hip_atomic_compare_exchange_strong(state + slot, &expected, PX_WRITING, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            px_store(w, home, data, slot);
-            __hip_atomic_store(state + slot, PX_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            sent = true;
-        }
-    }
-    return sent;
-}
-// `vacant` seats: true for those that took a path (`home` set).
-template <class W>
-DEV bool px_pop(bool vacant, W& w, uint32_t& home, lds_u32* queue, uint32_t* wave_scratch, uint32_t lane) {
-    lds_u32* state = queue;
-    const lds_u32* data = queue + kPxCap;
-    const uint32_t slot = px_assign(vacant, PX_FULL, state, wave_scratch, lane);
-    bool got = false;
-    if (slot < kPxCap) {
-        uint32_t expected = PX_FULL;
-        if (__hip_atomic_compare_exchange_strong(state + slot, &expected, PX_READING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            home = px_load(w, data, slot);
-            __hip_atomic_store(state + slot, PX_EMPTY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            got = true;
-        }
-    }
-    return got;
-}
-
-template <bool COUNT, bool LDS_TABLES>
-__global__ __launch_bounds__(BLOCK, PYR_SM_WAVES) void render_kernel_px(DevScene S0, RenderLaunch L) {
-    extern __shared__ float lds[];
-    const uint32_t SS = L.spectrum_samples;
-    const uint32_t spectral_rows = SS + 1 + kTapeEagerSlots;
-    TravStack stack;
-    int deep_levels[kMaxStackDepth];
-    stack.deep = deep_levels;
-    stack.lds = (lds_int*)(reinterpret_cast<int*>(lds + spectral_rows * BLOCK) + threadIdx.x);
-    stack.lds_entries = (int)L.stack_lds;
-    Counters cnt{};
-    const uint32_t lds_base_floats = (spectral_rows + L.stack_lds) * BLOCK;
-    const SceneView view = stage_scene<false>(S0, lds, lds_base_floats, true);
-    const DevScene S = stage_tables<LDS_TABLES ? 1 : 0>(S0, lds, lds_base_floats);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t total_waves = gridDim.x * (BLOCK / 64);
-    const int phase_lanes = (int)L.sm_phase_lanes, expose_lanes = (int)L.sm_expose_lanes;
-    uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
-    uint32_t* prepared_lds = reinterpret_cast<uint32_t*>(lds + lds_base_floats + (LDS_TABLES ? S0.lds_table_floats : 0));
-    float* spectral_values = lds + (SS + 1) * BLOCK + threadIdx.x;
-    spectral_values[kTapeOneSlot * BLOCK] = 1.0f;
-    lds_u32* px = (lds_u32*)(prepared_lds + 8 * L.tape_programs_lds + kTapeEagerSlots);
-    lds_u32* to_trav = px;
-    lds_u32* to_logic = px + kPxQueueWords;
-    lds_u32* control = px + 2 * kPxQueueWords; // [0] homes whose sequence has not ended, [1] next home to start, [2] give up
-    for (uint32_t i = threadIdx.x; i < kPxLdsWords; i += BLOCK) px[i] = i == 2 * kPxQueueWords ? (uint32_t)BLOCK : 0u; // control[0]: every home is alive
-    bool eager = false;
-    const uint32_t n_spectral = prepare_tape_tables(S0, S, L, prepared_lds, eager); // ends with a barrier: the queues are clear behind it
-    // two of the four waves walk the tree; which two alternates with the workgroup's round on its CU, so that a SIMD -- wave w of
-    // every resident workgroup -- gets both kinds of wave
-    const bool trav_role = ((wave + (blockIdx.x >> 8)) & 1u) == 0u;
-    Walker<COUNT, false, true> w;
-    w.stage = ST_VACANT;
-    w.tape_prepared = eager ? prepared_lds : nullptr;
-    uint32_t home = 0;
-    uint32_t idle_turns = 0, starved_turns = 0;
-    auto scene_view = [&](const RenderLaunch& Lp) {
-        const uint32_t rows = Lp.spectrum_samples + 1 + kTapeEagerSlots + Lp.stack_lds;
-        return stage_tables<LDS_TABLES ? 1 : 0, false>(scene_from_kernarg(S0), lds, rows * BLOCK);
-    };
-    auto alive = [&]() { return __hip_atomic_load(control + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; };
-    auto given_up = [&]() { return __hip_atomic_load(control + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u; };
-    // a turn in which a wave could do nothing at all; true when it is time to leave (the launch's error word is set then)
-    auto idle_turn = [&]() {
-        if (++idle_turns > kPxSpinLimit) {
-            *L.tape_overflow = 2u;
-            __hip_atomic_store(control + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(2);
-        return false;
-    };
-    PROF_DECL;
-    [[maybe_unused]] const unsigned long long t_wave0 = PROF_NOW();
-    [[maybe_unused]] unsigned long long t_exchange = 0;
-    [[maybe_unused]] unsigned long long census[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // PYR_PHASE_PROFILE: turns, and seats by state when a turn starts
-    if (trav_role) {
-        __builtin_amdgcn_s_setprio(PYR_PX_PRIO_T);
-        for (;;) {
-            // paths whose ray has ended go back to the logic waves; vacant seats take paths with a fresh ray
-            if (given_up()) break;
-            [[maybe_unused]] const unsigned long long t_x0 = PROF_NOW();
-            const bool finished = w.stage == ST_SHADE || w.stage == ST_NEE;
-            if (px_push(finished, w, home, to_logic, wave_list, lane)) w.stage = ST_VACANT;
-            if (px_pop(w.stage == ST_VACANT, w, home, to_trav, wave_list, lane)) {
-                w.stage = ST_TRAV;
-                w.t.node = 0, w.t.sp = 0; // trav_begin's restart, made by the logic wave; the tree's root
-            }
-            t_exchange += PROF_NOW() - t_x0;
-            const unsigned long long walking = ballot64(w.stage == ST_TRAV);
-#ifdef PYR_PHASE_PROFILE
-            census[0]++, census[1] += __popcll(walking), census[2] += __popcll(ballot64(w.stage == ST_VACANT)), census[3] += __popcll(ballot64(w.stage == ST_SHADE || w.stage == ST_NEE));
-#endif
-            if (walking == 0ull) { // nothing to walk: no work has arrived, or every seat waits for a slot of the queue back
-                if (!alive() || idle_turn()) break;
-                continue;
-            }
-            idle_turns = 0;
-#ifdef PYR_PHASE_PROFILE
-            const unsigned long long prof_t0_3 = clock64();
-#endif
-            w.t.inv = box_reciprocal(w.t.d);
-            trav_ray_signs(w.t);
-            for (int step = 0; step < PYR_PX_TRAV_STEPS; ++step) {
-                PROF_LANES(3, w.stage == ST_TRAV);
-                if (trav_step_lean<COUNT>(view, w.t, stack, cnt, w.stage == ST_TRAV)) w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
-            }
-            PROF_END(3);
-        }
-    } else {
-        for (;;) {
-            // ---- seats: take paths whose ray has ended; start the sequences of homes nobody has started yet
-            if (given_up()) break;
-            [[maybe_unused]] const unsigned long long t_x0 = PROF_NOW();
-            if (px_pop(w.stage == ST_VACANT, w, home, to_logic, wave_list, lane)) {
-                w.stage = w.t.shadow ? ST_NEE : ST_SHADE;
-                w.tape_column = blockIdx.x * BLOCK + home;
-            }
-            {
-                const unsigned long long vacant = ballot64(w.stage == ST_VACANT);
-                if (vacant != 0ull && __hip_atomic_load(control + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)BLOCK) {
-                    uint32_t first = 0;
-                    if (lane == (uint32_t)__builtin_ctzll(vacant)) first = __hip_atomic_fetch_add(control + 1, (uint32_t)__popcll(vacant), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    first = (uint32_t)__shfl((int)first, __builtin_ctzll(vacant));
-                    const uint32_t mine = first + (uint32_t)__popcll(vacant & ((1ull << lane) - 1ull));
-                    if (w.stage == ST_VACANT && mine < (uint32_t)BLOCK) {
-                        home = mine;
-                        w.stage = ST_NEW;
-                        w.chunk = L.chunk_begin + blockIdx.x * (BLOCK / 64) + (home >> 6);
-                        w.tape_column = blockIdx.x * BLOCK + home;
-                        w.n_ops = 0;
-                    }
-                }
-            }
-            t_exchange += PROF_NOW() - t_x0;
-            int nS = __popcll(ballot64(w.stage == ST_SHADE));
-            int nN = __popcll(ballot64(w.stage == ST_NEE));
-            int nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
-            const int nW = __popcll(ballot64(w.stage == ST_TRAV)); // paths that wait for a slot of the traversal queue
-#ifdef PYR_PHASE_PROFILE
-            census[0]++, census[1] += nS, census[2] += nN, census[3] += nE, census[4] += nW, census[5] += __popcll(ballot64(w.stage == ST_VACANT));
-#endif
-            if (max(max(nS, nN), nE) == 0) { // no phase to run: every seat is vacant or waits for a slot of the traversal queue
-                if (nW == 0 && !alive()) break;
-                const bool sent = px_push(w.stage == ST_TRAV, w, home, to_trav, wave_list, lane);
-                if (sent) w.stage = ST_VACANT;
-                if (ballot64(sent) != 0ull)
-                    idle_turns = 0;
-                else if (idle_turn())
-                    break;
-                continue;
-            }
-            idle_turns = 0;
-            // A logic wave that waits issues nothing, so it waits for fuller phases: a phase runs when its quorum of lanes wants it;
-            // only after PYR_PX_PATIENCE turns without any does the most wanted one run with what it has.
-            if (nE < expose_lanes && nS < phase_lanes && nN < phase_lanes && starved_turns < PYR_PX_PATIENCE) {
-                starved_turns++;
-                const bool sent = px_push(w.stage == ST_TRAV, w, home, to_trav, wave_list, lane);
-                if (sent) w.stage = ST_VACANT;
-                __builtin_amdgcn_s_sleep(8);
-                continue;
-            }
-            const bool impatient = starved_turns >= PYR_PX_PATIENCE;
-            starved_turns = 0;
-            Spectral spec{lds + home, SS};
-            if (nE >= expose_lanes || (impatient && nE != 0 && nE == max(max(nS, nN), nE))) {
-                __builtin_amdgcn_s_setprio(PYR_PX_PRIO_E);
-                PROF_BEGIN(0, w.stage == ST_EXPOSE || w.stage == ST_NEW);
-                const RenderLaunch& Lp = launch_from_kernarg(L);
-                const DevScene Sp = scene_view(Lp);
-                replay_tapes<COUNT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, home, wave_list, prepared_lds, spectral_values, n_spectral, eager, cnt);
-                const bool was_live = w.stage == ST_EXPOSE || w.stage == ST_NEW;
-                w.expose_and_restart(Sp, Lp, spec, cnt, home & 63u, total_waves);
-                const unsigned long long ended = ballot64(was_live && w.stage == ST_DONE);
-                if (ended != 0ull) { // these homes' sequences are over: their seats are vacant
-                    if (lane == (uint32_t)__builtin_ctzll(ended)) __hip_atomic_fetch_sub(control + 0, (uint32_t)__popcll(ended), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (w.stage == ST_DONE) w.stage = ST_VACANT;
-                }
-                PROF_END(0);
-                nS = __popcll(ballot64(w.stage == ST_SHADE));
-                nE = 0;
-            }
-            if (nS >= phase_lanes || (impatient && nS != 0 && nS == max(max(nS, nN), nE))) {
-                __builtin_amdgcn_s_setprio(PYR_PX_PRIO_S);
-                PROF_BEGIN(1, w.stage == ST_SHADE);
-                const RenderLaunch& Lp = launch_from_kernarg(L);
-                w.shade(scene_view(Lp), Lp, spec, cnt);
-                PROF_END(1);
-                nN = __popcll(ballot64(w.stage == ST_NEE));
-                nE = __popcll(ballot64(w.stage == ST_EXPOSE || w.stage == ST_NEW));
-                nS = 0;
-            }
-            if (nN >= phase_lanes || (impatient && nN != 0 && nN == max(max(nS, nN), nE))) {
-                __builtin_amdgcn_s_setprio(PYR_PX_PRIO_N);
-                PROF_BEGIN(2, w.stage == ST_NEE);
-                const RenderLaunch& Lp = launch_from_kernarg(L);
-                w.next_event(scene_view(Lp), Lp, spec, cnt);
-                PROF_END(2);
-            }
-            // ---- paths that now need a ray walked move to the traversal waves
-            [[maybe_unused]] const unsigned long long t_x1 = PROF_NOW();
-            if (px_push(w.stage == ST_TRAV, w, home, to_trav, wave_list, lane)) w.stage = ST_VACANT;
-            t_exchange += PROF_NOW() - t_x1;
-        }
-    }
-    PROF_EXTRA(trav_role ? 15 : 14, PROF_NOW() - t_wave0);
-    PROF_EXTRA(trav_role ? 12 : 13, t_exchange);
-#ifdef PYR_PHASE_PROFILE
-    for (int i = 0; i < 8; ++i) PROF_EXTRA((trav_role ? 16 : 24) + i, census[i]);
-#endif
-    PROF_FLUSH();
-    flush_counters<COUNT>(cnt, L.counters);
-}
+// (Round 4 built a path-exchange scheduler here -- render_kernel_px, commit f7c5438: two waves of a workgroup walk the tree, two run
+// the logic phases, a path's 35 words move between them through LDS slot arrays at the start and end of every ray; films and
+// counters equal to the stage scheduler's. 0.4-0.5x: throughput followed the queues' LDS capacity, 128 / 225 / 269 Msamples/s
+// at 16 / 32 / 64 slots against 592, and the copies cost more than half of what full lanes save. profiles/r04_phase_profile_px.txt
+// holds the seat census and the arithmetic. Deleted with the other schedulers that lost.)
 
 // ------------------------------------------------------------------------------------------------ work feed
 // Hands the items [0, n) of a batch to persistent waves. One cursor word serves only ~88 M atomics/s (they serialise in
@@ -3597,6 +3283,7 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(D
     flush_counters<COUNT>(cnt, L.counters);
 }
 
+#if PYR_TU != 1
 // ------------------------------------------------------------------------------------------------ film development
 // main.rs:315-327: every pixel spectrum -> spectrum_to_xyz (main.rs:352-418, trapezoid rule against the CIE observer
 // tables) -> linear sRGB -> sRGB u8. One thread per pixel; the film is read once (bins * 8 B per pixel), HBM-bound.
@@ -3789,7 +3476,7 @@ static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_p
 // hit's work among: with one or two per sample the online form wins (diamonds.lua, one wavelength, 256 bounces: 538 against 486).
 bool uses_hit_tape(const DevScene& scene, const RenderLaunch& launch) { return scene.needs_interpreter != 0 && scene.hit_tape != 0 && launch.spectrum_samples >= 4; }
 static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) {
-    return (launch.scheduler == 1 || launch.scheduler == 2) && (scene.needs_interpreter == 0 || uses_hit_tape(scene, launch));
+    return launch.scheduler == 1 && (scene.needs_interpreter == 0 || uses_hit_tape(scene, launch));
 }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
     const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
@@ -3797,34 +3484,46 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
     if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
     bytes += (size_t)scene.lds_table_floats * sizeof(float);
     if (uses_tape(scene, launch)) bytes += ((size_t)tape_programs_in_lds(scene) * 8 + kTapeEagerSlots) * sizeof(uint32_t);
-    if (launch.scheduler == 2) bytes += (size_t)kPxLdsWords * sizeof(uint32_t); // render_kernel_px's two path queues
     return bytes;
 }
 
+#endif // PYR_TU != 1
+
 using RenderKernel = void (*)(DevScene, RenderLaunch);
-template <bool C, bool I, bool L>
-static RenderKernel pick_tables(bool sm, bool lds_tables, bool hit_tape) {
+// A scene staged in LDS never has its tables staged too (api.cpp: lds_table_floats is only set for scenes that do not live in
+// LDS), so that combination is never instantiated.
+#if PYR_TU != 0
+// The interpreter builds of the stage scheduler (the synchronous walk is built without the interpreter: a scene with interpreter
+// programs always runs on the stage scheduler, which keeps the interpreter in line). HIT_TAPE: see device_scene.h TapeForm.
+RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tables, bool hit_tape) {
+    auto pick = [&](auto counters) -> RenderKernel {
+        constexpr bool C = decltype(counters)::value;
+        if (lds_scene) return hit_tape ? render_kernel_sm<C, true, true, false, true> : render_kernel_sm<C, true, true, false>;
+        if (hit_tape) return lds_tables ? render_kernel_sm<C, true, false, true, true> : render_kernel_sm<C, true, false, false, true>;
+        return lds_tables ? render_kernel_sm<C, true, false, true> : render_kernel_sm<C, true, false, false>;
+    };
+    return with_counters ? pick(std::true_type{}) : pick(std::false_type{});
+}
+#else
+RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tables, bool hit_tape);
+#endif
+
+#if PYR_TU != 1
+static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables, bool hit_tape) {
 #ifdef PYR_DEV_ONLY_SM // developer builds for reading the ISA (tools/asm_sm.sh): only the kernel the BASELINE meshes run is instantiated
     return render_kernel_sm<false, false, false, true>;
 #endif
 #ifdef PYR_DEV_ONLY_SM_INTERP // ... or only the interpreter build the reference's textures example runs
-    return render_kernel_sm<false, true, true, false>;
+    return render_kernel_sm<false, true, true, false, true>;
 #endif
-    // the synchronous walk is built without the interpreter only: a scene with interpreter programs runs on the stage scheduler,
-    // which keeps the interpreter in line (api.cpp render_batches routes it there; this keeps the out-of-line builds out of the library)
-    if constexpr (I) {
-        if (hit_tape) return lds_tables ? render_kernel_sm<C, true, L, true, true> : render_kernel_sm<C, true, L, false, true>;
-    }
-    if (sm || I) return lds_tables ? render_kernel_sm<C, I, L, true> : render_kernel_sm<C, I, L, false>;
-    return lds_tables ? render_kernel<C, false, L, true> : render_kernel<C, false, L, false>;
-}
-template <bool C, bool I>
-static RenderKernel pick_scene(bool sm, bool lds_scene, bool lds_tables, bool hit_tape) {
-    return lds_scene ? pick_tables<C, I, true>(sm, lds_tables, hit_tape) : pick_tables<C, I, false>(sm, lds_tables, hit_tape);
-}
-static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables, bool hit_tape) {
-    if (with_counters) return interp ? pick_scene<true, true>(sm, lds_scene, lds_tables, hit_tape) : pick_scene<true, false>(sm, lds_scene, lds_tables, false);
-    return interp ? pick_scene<false, true>(sm, lds_scene, lds_tables, hit_tape) : pick_scene<false, false>(sm, lds_scene, lds_tables, false);
+    if (interp) return pick_interp_kernel(with_counters, lds_scene, lds_tables, hit_tape);
+    auto pick = [&](auto counters) -> RenderKernel {
+        constexpr bool C = decltype(counters)::value;
+        if (lds_scene) return sm ? render_kernel_sm<C, false, true, false> : render_kernel<C, false, true, false>;
+        if (sm) return lds_tables ? render_kernel_sm<C, false, false, true> : render_kernel_sm<C, false, false, false>;
+        return lds_tables ? render_kernel<C, false, false, true> : render_kernel<C, false, false, false>;
+    };
+    return with_counters ? pick(std::true_type{}) : pick(std::false_type{});
 }
 
 bool scene_is_lds_resident(const DevScene& scene) { return scene_fits_lds(scene); }
@@ -3838,11 +3537,8 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.stack_lds = 0;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernels are built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
-    // the path-exchange scheduler walks four-child trees with triangle pairs only and has no interpreter form: anything else
-    // runs on the stage scheduler
-    if (launch.scheduler == 2 && (scene.needs_interpreter != 0 || scene.wide_pair_nodes == nullptr || scene_fits_lds(scene))) launch.scheduler = 1;
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
-    launch.stack_lds = launch.scheduler != 0 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? (uses_hit_tape(scene, launch) ? PYR_SM_WAVES_HIT_TAPE : PYR_SM_WAVES_INTERP) : PYR_SM_WAVES)
+    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? (uses_hit_tape(scene, launch) ? PYR_SM_WAVES_HIT_TAPE : PYR_SM_WAVES_INTERP) : PYR_SM_WAVES)
                                              : scene.stack_depth;
     // a scene staged in LDS is a few dozen nodes: its whole stack is kept in LDS (the kernels built for such scenes have no
     // scratch part: TravStack::deep is one entry), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below applies
@@ -3856,14 +3552,6 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     if (chunks == 0) return PYR_OK;
     RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0,
                                       launch.scheduler == 1 && uses_hit_tape(scene, launch));
-    if (launch.scheduler == 2) {
-        static const RenderKernel px_variants[2][2] = {{render_kernel_px<false, false>, render_kernel_px<false, true>}, {render_kernel_px<true, false>, render_kernel_px<true, true>}};
-        kernel = px_variants[with_counters ? 1 : 0][scene.lds_table_floats != 0 ? 1 : 0];
-        if (launch.stack_lds < 4) {
-            g_kernel_error = "PYRITE_SCHEDULER=px needs at least four traversal stack levels in LDS";
-            return PYR_ERR_UNSUPPORTED;
-        }
-    }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
@@ -3931,9 +3619,11 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
     return PYR_OK;
 }
 
+#endif // PYR_TU != 1
+
 } // namespace pyr
 
-#ifdef PYR_PHASE_PROFILE
+#if defined(PYR_PHASE_PROFILE) && PYR_TU != 1
 extern "C" int pyr_debug_phase_profile32(unsigned long long* out32, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pyr::g_phase_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;

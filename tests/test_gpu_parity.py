@@ -340,33 +340,6 @@ def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
         assert gcount["exposures"] < gcount["samples"] * 10  # dispersed paths expose the hero wavelength only
 
 
-@pytest.mark.parametrize("glass", [False, True])
-def test_path_exchange_scheduler_on_a_c3_shaped_scene(glass, gpu_lib, monkeypatch):
-    """render_kernel_px (two waves of a workgroup walk the tree, two run the logic phases, PATHS move between them through LDS
-    queues at the start and the end of every ray) on the C3 / C5-shaped scene: the oracle's film and path counters, ragged
-    tiles, with and without the counters build -- and, box test for box test, the stage scheduler's counters."""
-    from pyrite_amd.renderer import Camera, Renderer, World
-
-    monkeypatch.setenv("PYRITE_SCHEDULER", "px")
-    project = scenes.c3_mesh_in_box(width=50, height=30, pixel_samples=5, glass=glass, bounces=20 if glass else None)
-    world = World(scenes.c3_flat(segments=96, sides=48, glass=glass))
-    r = Renderer.from_project(project["renderer"], seed=13)
-    cam = Camera.from_project(project["camera"])
-    gfilm, plain, cfilm = r.new_film(50, 30), r.new_film(50, 30), r.new_film(50, 30)
-    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
-    gcount = r.render(gfilm, cam, world, counters=True)
-    r.render(plain, cam, world)
-    assert_parity(gfilm, cfilm)
-    assert_parity(plain, cfilm)
-    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
-        assert gcount[key] == ccount[key], key
-    monkeypatch.setenv("PYRITE_SCHEDULER", "sm")
-    sm_film = r.new_film(50, 30)
-    scount = r.render(sm_film, cam, world, counters=True)
-    assert scount == gcount  # the same steps, box for box: the traversal is the stage scheduler's
-    assert_parity(sm_film, gfilm)
-
-
 def test_stage_scheduler_on_an_lds_resident_scene_with_a_one_level_lds_stack(gpu_lib, monkeypatch):
     """the kernels built for scenes staged in LDS have no scratch part of the traversal stack (one entry), so the
     launcher must keep the WHOLE stack in LDS for such scenes whatever PYRITE_LDS_STACK or the budget say -- also when the
