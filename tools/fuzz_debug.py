@@ -18,7 +18,7 @@ W, H = project["image"]["width"], project["image"]["height"]
 print("flat: tris %d spheres %d planes %d lamps %d textures %d" % (len(world.flat.tri_material), len(world.flat.spheres), len(world.flat.planes), len(world.flat.lamps), len(world.flat.textures)))
 cfilm = r.new_film(W, H)
 cc = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
-for sched in ("sync", "sm", "wf"):
+for sched in ("sync", "sm"):
     for wide in ("1", "0"):
         os.environ["PYRITE_SCHEDULER"], os.environ["PYRITE_WIDE_BVH"] = sched, wide
         w2 = World(world.flat)

@@ -26,7 +26,7 @@ else:
 cfilm = r.new_film(W, H)
 cc = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
 for rep in range(repeats):
-    for sched in ("sm", "wf", "sync"):
+    for sched in ("sm", "sync"):
         os.environ["PYRITE_SCHEDULER"] = sched
         g = r.new_film(W, H)
         gc = r.render(g, cam, world, counters=True)
