@@ -180,8 +180,18 @@ DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
         o.tape_form = TAPE_FORM_NONE;
         if (p.output_kind == PYR_OUTPUT_NUMBER && p.num_instrs != 0) {
             const PyrInstr& last = I[p.num_instrs - 1];
+            // a function of the wavelength alone, numbers only: the subset kernels.hip lambda_eval interprets
+            bool lambda = true;
+            for (uint32_t k = 0; k < p.num_instrs; ++k) {
+                const PyrInstr& ins = I[k];
+                const bool number_op = ins.op == PYR_OP_NUMBER || ins.op == PYR_OP_SPECTRUM || ins.op == PYR_OP_BLACKBODY || ins.op == PYR_OP_CLAMP ||
+                                       ((ins.op == PYR_OP_BINARY || ins.op == PYR_OP_MIX) && ins.value_type == PYR_VT_NUMBER);
+                if (!number_op || (ins.deps & (PYR_DEP_NORMAL | PYR_DEP_INCIDENT | PYR_DEP_TEXTURE)) != 0u) lambda = false;
+            }
             if (dependent == 0)
                 o.tape_form = TAPE_FORM_HIT_VALUE;
+            else if (lambda)
+                o.tape_form = TAPE_FORM_LAMBDA;
             else if (dependent == 1 && last.op == PYR_OP_RGB_SPECTRUM && operand_is_wavelength(last.x) && last.output == p.output_reg) {
                 o.tape_form = TAPE_FORM_HIT_RGB;
                 o.tape_rgb_reg = last.a;
@@ -569,8 +579,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.hit_tape = v.rgb_records = 0;
     if (needs_interpreter) {
         bool ok = d->num_programs <= 128;
-        uint32_t fast_programs = 0;
-        for (const DevProgram& pr : programs) fast_programs += pr.kind == PYR_PROGRAM_INSTRUCTIONS && pr.fast != FAST_NONE ? 1u : 0u;
+        uint32_t fast_programs = 0; // programs that take a value slot of the replay: fast shapes and LAMBDA forms
+        for (const DevProgram& pr : programs)
+            fast_programs += pr.kind == PYR_PROGRAM_INSTRUCTIONS && (pr.fast != FAST_NONE || pr.tape_form == TAPE_FORM_LAMBDA) ? 1u : 0u;
         auto colour = [&](uint32_t id) {
             if (id >= programs.size()) return;
             const DevProgram& pr = programs[id];

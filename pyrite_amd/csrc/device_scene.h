@@ -69,9 +69,12 @@ enum FastProgram : uint32_t {
 //   HIT_RGB    everything but a closing RgbSpectrumValue(wavelength, rgb) is independent of the wavelength (a colour texture, an
 //              rgb() expression): the interpreter evaluates the rgb register once per hit, the record carries its three components
 //              and the replay forms rgb . RGB_basis(wavelength) per wavelength, the very sum execution_context.rs:140-152 forms;
-//   NONE       needs an interpreter run per wavelength (a blackbody, a mix of spectra by a fresnel term, ...): a scene with such a
-//              COLOUR program keeps the online form of round 3 (Walker::contribute_pending).
-enum TapeForm : uint32_t { TAPE_FORM_DIRECT = 0, TAPE_FORM_HIT_VALUE = 1, TAPE_FORM_HIT_RGB = 2, TAPE_FORM_NONE = 3 };
+//   LAMBDA     a function of the wavelength alone made of numbers only (`blackbody(4000) * 3`, a product or mix of spectra): like a
+//              fast shape it gets a value slot -- the replay evaluates it once per item with a small number-only interpreter
+//              (kernels.hip lambda_eval) -- and the record names it;
+//   NONE       needs an interpreter run per hit AND wavelength (a mix of spectra by a fresnel term, a texture times a spectrum): a
+//              scene with such a COLOUR program keeps the online form of round 3 (Walker::contribute_pending).
+enum TapeForm : uint32_t { TAPE_FORM_DIRECT = 0, TAPE_FORM_HIT_VALUE = 1, TAPE_FORM_HIT_RGB = 2, TAPE_FORM_NONE = 3, TAPE_FORM_LAMBDA = 4 };
 
 struct DevProgram {
     uint32_t kind; // PyrProgramKind

@@ -2411,7 +2411,7 @@ struct Walker {
                 Vm vm;
                 float cp = c_cp, hit_value = 1.0f;
                 const DevProgram colour = S.programs[c_color];
-                const bool run_colour = colour.kind != PYR_PROGRAM_CONSTANT && colour.fast == FAST_NONE; // HIT_VALUE or HIT_RGB: the interpreter runs its hit part
+                const bool run_colour = colour.tape_form == TAPE_FORM_HIT_VALUE || colour.tape_form == TAPE_FORM_HIT_RGB; // the interpreter runs its hit part; everything else is looked up by the replay
                 // job 0: the probability program in full (it is evaluated for the hero wavelength only); job 1: the colour program's
                 // instructions that do not depend on the wavelength -- all of a HIT_VALUE program, all but the closing one of a HIT_RGB
                 for (uint32_t job = c_probability >= 0 ? 0u : 1u; job < 2u; ++job) {
@@ -2728,6 +2728,49 @@ struct Walker {
     }
 };
 
+// A LAMBDA program (device_scene.h TapeForm) at one wavelength: the number-only subset of Vm::step -- the same expressions in the
+// same order (program/execution_context.rs:81-283) -- on a register file of its own. Runs once per replay item and slot, in uniform
+// control flow (every lane of the wave interprets the same program).
+DEV float lambda_eval(const DevScene& S, const DevProgram& p, float wavelength) {
+    float num[PYR_MAX_NUMBER_REGISTERS];
+    auto value = [&](const PyrOperand& o) -> float {
+        if (o.kind == PYR_OPERAND_CONSTANT) return __uint_as_float(o.bits);
+        if (o.kind == PYR_OPERAND_INPUT) return wavelength;
+        return num[o.bits & (PYR_MAX_NUMBER_REGISTERS - 1)];
+    };
+    for (uint32_t k = 0; k < p.num_instrs; ++k) {
+        const PyrInstr& ins = S.instrs[p.first_instr + k];
+        float r = 0.0f;
+        switch (ins.op) {
+        case PYR_OP_NUMBER: r = __uint_as_float(ins.x.bits); break;
+        case PYR_OP_SPECTRUM: r = spectrum_get(S, ins.a, value(ins.x)); break;
+        case PYR_OP_BLACKBODY: {
+            const float wl = value(ins.x), temp = value(ins.y);
+            r = blackbody(wl, temp);
+            break;
+        }
+        case PYR_OP_MIX: {
+            const float amount = fmaxf(fminf(value(ins.x), 1.0f), 0.0f);
+            const float l = num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], rr = num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)];
+            r = l * (1.0f - amount) + rr * amount;
+            break;
+        }
+        case PYR_OP_BINARY: {
+            const float l = num[ins.a & (PYR_MAX_NUMBER_REGISTERS - 1)], rr = num[ins.b & (PYR_MAX_NUMBER_REGISTERS - 1)];
+            r = ins.operator_ == PYR_BIN_ADD ? l + rr : (ins.operator_ == PYR_BIN_SUB ? l - rr : (ins.operator_ == PYR_BIN_MUL ? l * rr : l / rr));
+            break;
+        }
+        default: { // PYR_OP_CLAMP (api.cpp admits no other opcode into a LAMBDA program)
+            const float v = value(ins.x), mn = value(ins.y), mx = value(ins.z);
+            r = fmaxf(fminf(v, mx), mn);
+            break;
+        }
+        }
+        num[ins.output & (PYR_MAX_NUMBER_REGISTERS - 1)] = r;
+    }
+    return num[p.output_reg & (PYR_MAX_NUMBER_REGISTERS - 1)];
+}
+
 // Replays the tapes of the wave's finished lanes (`exposing`) and exposes the film: contribute + Film::expose for every
 // (path, wavelength) pair, one pair per lane. Item i of the wave is wavelength i % S of the (i / S)-th finished lane; index
 // S - 1 stands for the hero (kept in the lane's registers), 0 .. S - 2 for the companions in LDS. A path that dispersed
@@ -2821,7 +2864,9 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 #ifdef PYR_REPLAY_NOEAGER_EVAL // timing ablation (the film is wrong): what the per-item look-ups of the spectrum-reading programs cost
                 v = wl * 1.0e-3f;
 #else
-                if (format == PYR_SPECTRUM_ARRAY && count != 0u) {
+                if (RGB && mode == 0xFFu) { // (uniform) a LAMBDA program: interpreted once per item (hit-tape scenes only)
+                    v = lambda_eval(S, S.programs[slot_program[slot]], wl);
+                } else if (format == PYR_SPECTRUM_ARRAY && count != 0u) {
                     if (e[3] != grid_min || e[4] != grid_max || count != grid_count) { // (uniform) another grid than the previous slot's
                         grid_min = e[3], grid_max = e[4], grid_count = count;
                         const float lo = __uint_as_float(grid_min), hi = __uint_as_float(grid_max);
@@ -2841,7 +2886,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                     v = spectrum_eval(sp, data, wl);
                 }
 #endif
-                spectral_values[slot * BLOCK] = mode == FAST_SPECTRUM ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
+                spectral_values[slot * BLOCK] = (mode == FAST_SPECTRUM || mode == 0xFFu) ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
             }
             if (RGB && S.rgb_records != 0) { // (uniform) the RGB basis at this item's wavelength: RgbSpectrumValue's look-up, execution_context.rs:140-152
                 float resp[3] = {0.0f, 0.0f, 0.0f};
@@ -2979,10 +3024,13 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
 DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const RenderLaunch& L, uint32_t* prepared_lds, bool& eager) {
     // Programs that evaluate alike -- the same shape, factor and spectrum (a scene compiles one colour program per use: C3's
     // three white walls are three programs over one spectrum) -- share a value slot: the replay looks a slot up once per item.
-    auto reads_spectrum = [&](uint32_t i) { return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && S0.programs[i].fast != FAST_NONE; };
+    // (a LAMBDA program -- device_scene.h TapeForm: a number-only function of the wavelength, hit-tape scenes -- takes a slot of its own)
+    auto reads_spectrum = [&](uint32_t i) {
+        return S0.programs[i].kind != PYR_PROGRAM_CONSTANT && (S0.programs[i].fast != FAST_NONE || (S0.hit_tape != 0 && S0.programs[i].tape_form == TAPE_FORM_LAMBDA));
+    };
     auto alike = [&](uint32_t i, uint32_t j) {
         const DevProgram &a = S0.programs[i], &b = S0.programs[j];
-        return a.fast == b.fast && __float_as_uint(a.fast_scale) == __float_as_uint(b.fast_scale) && a.fast_spectrum == b.fast_spectrum;
+        return a.fast != FAST_NONE && a.fast == b.fast && __float_as_uint(a.fast_scale) == __float_as_uint(b.fast_scale) && a.fast_spectrum == b.fast_spectrum;
     };
     auto first_alike = [&](uint32_t i) { // the first spectrum-reading program that evaluates like program i
         for (uint32_t j = 0; j < i; ++j)
