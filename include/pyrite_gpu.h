@@ -359,7 +359,7 @@ int pyr_render_simple(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
 
 /* Same, but `film_device` is DEVICE memory on the scene's device and the work is enqueued on `hip_stream`
  * (a hipStream_t, NULL = default stream) without synchronising: the caller synchronises the stream.
- * A PyrScene owns device-side working memory (counters, the spectral tape, the path pool) that serves one render at a
+ * A PyrScene owns device-side working memory (counters, the spectral tape) that serves one render at a
  * time: renders of ONE scene must be issued on one stream (or otherwise ordered); different scenes are independent. */
 int pyr_render_simple_device(PyrScene* scene, const PyrCamera* camera, const PyrFilmDesc* film,
                              const PyrRenderParams* params, PyrGrain* film_device, void* hip_stream);

@@ -2225,10 +2225,9 @@ DEV bool trav_step_lean(const SceneView& view, Trav& t, TravStack& stack, Counte
     return done;
 }
 
-// Per-path state of the resumable integrator and the code of its phases; shared by the stage-scheduled kernel (state in
-// registers) and the wavefront kernels (state in HBM between phases).
+// Per-path state of the resumable integrator and the code of its phases (the stage-scheduled kernel keeps it in registers).
 // Spectral tape (TAPE builds: the stage-scheduled kernel on scenes without interpreter programs, i.e. every BASELINE
-// config). Without the interpreter a colour program is a function of the wavelength alone, and nothing a path decides
+// config; since round 4 also on scenes WITH interpreter programs whose colour programs have a tape form, see tape_pending). Without the interpreter a colour program is a function of the wavelength alone, and nothing a path decides
 // depends on its brightness or reflectance (the reference has no Russian roulette; only the hero wavelength's value enters
 // the geometry, through dispersion). So `contribute` (renderer/algorithm.rs:14-100) need not run while the path is walked,
 // in phases that execute at a third of the wave's width: each path only records what contribute would be applied to --
