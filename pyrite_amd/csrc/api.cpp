@@ -579,9 +579,23 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.hit_tape = v.rgb_records = 0;
     if (needs_interpreter) {
         bool ok = d->num_programs <= 128;
-        uint32_t fast_programs = 0; // programs that take a value slot of the replay: fast shapes and LAMBDA forms
-        for (const DevProgram& pr : programs)
-            fast_programs += pr.kind == PYR_PROGRAM_INSTRUCTIONS && (pr.fast != FAST_NONE || pr.tape_form == TAPE_FORM_LAMBDA) ? 1u : 0u;
+        // value slots of the replay: one per LAMBDA program and one per DISTINCT fast shape -- programs of the same shape, factor and
+        // spectrum share a slot (kernels.hip prepare_tape_tables `alike`: C3's three white walls are three programs over one spectrum)
+        uint32_t fast_programs = 0;
+        for (size_t i = 0; i < programs.size(); ++i) {
+            const DevProgram& pr = programs[i];
+            if (pr.kind != PYR_PROGRAM_INSTRUCTIONS) continue;
+            if (pr.tape_form == TAPE_FORM_LAMBDA) {
+                fast_programs += 1u;
+            } else if (pr.fast != FAST_NONE) {
+                bool seen = false;
+                for (size_t j = 0; j < i && !seen; ++j) {
+                    const DevProgram& q = programs[j];
+                    seen = q.kind == PYR_PROGRAM_INSTRUCTIONS && q.fast == pr.fast && q.fast_spectrum == pr.fast_spectrum && std::memcmp(&q.fast_scale, &pr.fast_scale, sizeof(float)) == 0;
+                }
+                fast_programs += seen ? 0u : 1u;
+            }
+        }
         auto colour = [&](uint32_t id) {
             if (id >= programs.size()) return;
             const DevProgram& pr = programs[id];

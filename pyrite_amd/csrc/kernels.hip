@@ -2347,6 +2347,16 @@ struct Walker {
         c_kind = kind, c_color = color, c_probability = probability, c_cp = cp, c_use_outer = use_outer, c_outer = outer, c_companions = companions;
         c_normal = normal, c_incident = incident, c_tx = tx, c_ty = ty;
     }
+    // What the phases noted lives for one turn of the stage loop only: applied (or recorded) right behind the phases, then CLEARED --
+    // to constants, on every turn -- so that the compiler sees none of these sixteen words alive across the loop's back edge and the
+    // traversal phase does not carry them in registers (the compiler cannot tell that they are only read while c_kind says so).
+    DEV void contribution_clear() {
+        c_kind = CONTRIB_NONE, c_color = 0u, c_probability = -1;
+        c_cp = 1.0f, c_outer = 1.0f, c_scale = 1.0f;
+        c_use_outer = false, c_companions = false, c_has_scale = false;
+        c_normal = mk(0, 0, 0), c_incident = mk(0, 0, 0);
+        c_tx = 0.0f, c_ty = 0.0f;
+    }
     DEV void contribute_pending(const DevScene& S, const RenderLaunch& L, Spectral& spec) {
         if constexpr (INTERP && !TAPE) {
             const uint32_t n_add = L.spectrum_samples - 1;
@@ -3063,18 +3073,17 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
     return eager ? n_spectral : 0u;
 }
 
-// Interpreter builds keep the program interpreter in line (Walker::contribute_pending): register files, a bicubic texture
-// look-up's sixteen texels and the walker do not fit 128 VGPRs -- at four waves per SIMD the kernel spilled 340 of them
-// and spent 87 % of its wave cycles waiting for scratch (profiles/r03_textures_interpreter_baseline.txt) -- so they are built for
-// PYR_SM_WAVES_INTERP waves per SIMD.
+// Interpreter builds keep the program interpreter in line (an out-of-line copy spills the walker around every call: rounds 3 and 4)
+// and are built for THREE waves per SIMD (168 VGPRs). Round 3 needed two (252 VGPRs: the pending contribution's sixteen words were
+// carried across the stage loop; contribution_clear() ends that, 256 -> 208 VGPRs unconstrained); measured in round 4 at 2 / 3 / 4
+// waves, hit tape: spheres 962 / 995 / 830, lamps 1005 / 1111 / 1063, textures 894 / 929 / 871 Msamples/s; the C3 mesh with a
+// fresnel-coated rgb() material (tools/bench_interp_mesh.py), where the tree walk waits for memory: 246 / 320 / 308.
 #ifndef PYR_SM_WAVES_INTERP
-#define PYR_SM_WAVES_INTERP 2
+#define PYR_SM_WAVES_INTERP 3
 #endif
-#ifndef PYR_SM_WAVES_HIT_TAPE
-#define PYR_SM_WAVES_HIT_TAPE 2 // interpreter builds that record a tape (HIT_TAPE)
-#endif
+constexpr int sm_waves(bool interp, bool /*lds_scene*/, bool /*hit_tape*/) { return interp ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES; }
 template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES, bool HIT_TAPE = false>
-__global__ __launch_bounds__(BLOCK, INTERP ? (HIT_TAPE ? PYR_SM_WAVES_HIT_TAPE : PYR_SM_WAVES_INTERP) : PYR_SM_WAVES) void render_kernel_sm(DevScene S0, RenderLaunch L) {
+__global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     static_assert(INTERP || !HIT_TAPE, "HIT_TAPE is a form of the interpreter build");
     constexpr bool TAPE = !INTERP || HIT_TAPE; // see "Spectral tape"; interpreter builds: scenes whose colour programs all have a tape form
@@ -3184,6 +3193,7 @@ __global__ __launch_bounds__(BLOCK, INTERP ? (HIT_TAPE ? PYR_SM_WAVES_HIT_TAPE :
                     w.contribute_pending(scene_view(Lp), Lp, spec);
                 PROF_EXTRA(12, PROF_NOW() - t_c0);
             }
+            w.contribution_clear();
         }
         // ---- TRAV: sm_trav_steps node / leaf steps of every lane with a ray in flight
         if (nT >= phase_lanes || nT == max(max(nT, nS), max(nN, nE))) {
@@ -3585,7 +3595,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
     // the stage-scheduled kernels are built for 4 waves per SIMD (__launch_bounds__(BLOCK, 4))
     launch.tape_programs_lds = uses_tape(scene, launch) ? tape_programs_in_lds(scene) : 0u;
-    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), scene.needs_interpreter != 0 ? (uses_hit_tape(scene, launch) ? PYR_SM_WAVES_HIT_TAPE : PYR_SM_WAVES_INTERP) : PYR_SM_WAVES)
+    launch.stack_lds = launch.scheduler == 1 ? short_stack_levels(scene, render_lds_bytes(scene, launch), (uint32_t)sm_waves(scene.needs_interpreter != 0, scene_fits_lds(scene), uses_hit_tape(scene, launch)))
                                              : scene.stack_depth;
     // a scene staged in LDS is a few dozen nodes: its whole stack is kept in LDS (the kernels built for such scenes have no
     // scratch part: TravStack::deep is one entry), whatever the budget or PYRITE_LDS_STACK say; the 160 KB check below applies

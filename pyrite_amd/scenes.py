@@ -173,14 +173,15 @@ def _mesh_dict_from_arrays(name, positions, normals):
             "objects": [{"name": name, "polys": polys}]}
 
 
-def c3_mesh_in_box(width=1920, height=1080, pixel_samples=1024, segments=640, sides=640, glass=False, bounces=None):
-    """C3 (and C5 with glass=True). Built through FlatScene's bulk triangle path: see `c3_flat`."""
+def c3_mesh_in_box(width=1920, height=1080, pixel_samples=1024, segments=640, sides=640, glass=False, bounces=None, mesh_material=None):
+    """C3 (and C5 with glass=True). Built through FlatScene's bulk triangle path: see `c3_flat`. `mesh_material` (development:
+    tools/bench_interp_mesh.py) gives the mesh another material, e.g. one that runs interpreter programs."""
     return {"image": {"width": width, "height": height}, "renderer": _simple(pixel_samples, bounces=bounces),
             "camera": cornell_camera(scale=10.0), "world": None,
-            "flat": lambda: c3_flat(segments=segments, sides=sides, glass=glass)}
+            "flat": lambda: c3_flat(segments=segments, sides=sides, glass=glass, mesh_material=mesh_material)}
 
 
-def c3_flat(segments=640, sides=640, glass=False):
+def c3_flat(segments=640, sides=640, glass=False, mesh_material=None):
     from .compiler import FlatScene  # local import: scenes are plain data otherwise
 
     m = cornell_materials()
@@ -188,7 +189,9 @@ def c3_flat(segments=640, sides=640, glass=False):
     flat = FlatScene()
     flat.add_world({"objects": [shape.mesh(file=box, scale=10.0, materials=_box_materials(m, [o["name"] for o in box["objects"]]))]})
     dragon = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dragon.obj")
-    if glass:
+    if mesh_material is not None:
+        pass
+    elif glass:
         mesh_material = {"surface": material.refractive(ior=1.5, dispersion=0.01371, color=1)}  # dragon.lua:30-35
     else:
         mesh_material = {"surface": material.diffuse(color=0.8)}
