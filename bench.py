@@ -21,8 +21,9 @@ Extra objects on the line:
                 the kernel's average launch duration measured with HIP events on the launch stream, against the 8 TB/s
                 HBM3E peak. THIS `frac` is the number north_star's ">= 40 % of the HBM-read roofline" is compared with for
                 the render; `traversal_roofline.frac` is the same for World::intersect alone. `traffic` = PMC HBM bytes per
-                launch from the rocprofv3 --pmc passes committed under profiles/ (null when there is none for this
-                workload); `measured_hbm_GBps` = traffic / kernel time, what the fabric really moved. `bytes_per_sample` is
+                launch, measured in THIS run (N = 1, full workload): two child passes of one launch under `rocprofv3 --pmc`
+                (FETCH_SIZE, WRITE_SIZE; ~25 s each), falling back to the passes committed under profiles/ when rocprofv3
+                is missing or --no-live-traffic is given (`traffic_source` says which); `measured_hbm_GBps` = traffic / kernel time, what the fabric really moved. `bytes_per_sample` is
                 printed because the algorithmic figure rewards wasted tests: a better tree lowers both it and `achieved`.
   c2            (N = 1, default workload only) configs[1], the 36-triangle Cornell box at 1024^2 x 256 spp, three steps: its
                 scene lives in LDS, so its algorithmic bytes are LDS reads and the object says "bound": "lds".
@@ -244,6 +245,55 @@ def load_traffic(workload):
     return None, None, None
 
 
+TRAFFIC_FORMULA = ("(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM' (gfx950 tallies 128-B requests at "
+                   "64 B); WRITE_SIZE is exact for float atomics; Infinity-Cache hits are counted (the counters sit at the L2's fabric side)")
+
+
+def live_traffic(workload, seed, kernel_part, pass_seconds=300):
+    """PMC traffic of THIS build on THIS box: two child runs of this file's one launch under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, no trace domain beside them, the program itself behind `--`; MI355X_MICROARCH.md "HBM").
+    -> (bytes per launch, a description) or (None, why not). The children are ordinary child processes; the parent's scene
+    stays where it is (a few GB of 288)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None, "rocprofv3 is not on PATH"
+    env = dict(os.environ, TMPDIR="/tmp")
+    kb, kernel, t0 = {}, None, time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="pyr_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload, "--steps", "1", "--warmup", "0", "--seed", str(seed), "--no-cpu-baseline", "--no-traversal", "--no-c2", "--no-c5",
+               "--no-c1", "--no-live-traffic"]
+        try:
+            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=pass_seconds)
+            if done.returncode != 0:
+                return None, "the %s pass ended with code %d: %s" % (counter, done.returncode, done.stdout.decode(errors="replace")[-200:])
+            values = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if kernel_part in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            values.append(float(row["Counter_Value"]))
+                            kernel = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not values:
+                return None, "the %s pass has no row of %s" % (counter, kernel_part)
+            kb[counter] = sum(values) / len(values)
+        except subprocess.TimeoutExpired:
+            return None, "the %s pass took more than %d s" % (counter, pass_seconds)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0), (
+        "live: rocprofv3 --pmc FETCH_SIZE (%.1f KB) and --pmc WRITE_SIZE (%.1f KB), separate passes of one launch of this build on this box "
+        "(`bench.py --workload %s --steps 1 --warmup 0 --seed %d`, %s; %.0f s for both); %s" % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], workload, seed, kernel,
+                                                                                      time.time() - t0, TRAFFIC_FORMULA))
+
+
 class Workload:
     """One BASELINE configuration on this rank's GPU: scene uploaded, film described, ready to be stepped."""
 
@@ -335,19 +385,27 @@ class Workload:
         staged = forced == "sm" or (forced != "sync" and not self.lds_resident)
         return "render_kernel_sm (stage-scheduled)" if staged else "render_kernel (bounce-synchronous)"
 
-    def roofline(self, counters, kernel_ms, launches_per_step):
+    def roofline(self, counters, kernel_ms, launches_per_step, live=None):
+        """`live` = (bytes per launch, description) from live_traffic() of this run, or (None, why there is none)."""
         samples = self.width * self.height * self.spp
         traversal = 32 * counters["box_tests"] + 36 * counters["triangle_tests"] + 16 * (counters["sphere_tests"] + counters["plane_tests"])
         total = algorithmic_bytes(counters)
         achieved = total / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_ms, traffic_source = load_traffic(self.name)
-        if self.reduced or self.world_size != 1:
+        committed = traffic
+        if live is not None and live[0] is not None:
+            traffic, traffic_ms, traffic_source = live[0], None, live[1]
+            if committed:
+                traffic_source += "; the committed passes (profiles/traffic.json) said %d" % committed
+        elif self.reduced or self.world_size != 1:
             traffic = traffic_ms = None  # the committed counters are for the full single-GPU launch
             traffic_source = None
         elif traffic is not None and traffic_ms and abs(traffic_ms - kernel_ms) > 0.02 * kernel_ms:
             # the kernel the counters were collected on took another time than this run's: not the same build any more
             traffic_source = "dropped: %s took %.1f ms per launch, this run %.1f ms" % (traffic_source, traffic_ms, kernel_ms)
             traffic = traffic_ms = None
+        if live is not None and live[0] is None:
+            traffic_source = "%s; no live passes in this run: %s" % (traffic_source, live[1])
         out = {
             "bound": "lds" if self.lds_resident else "hbm",
             "achieved": round(achieved, 1),
@@ -435,6 +493,8 @@ def main():
     ap.add_argument("--no-traversal", action="store_true", help="skip the BVH-traversal roofline measurement on the C3 scene")
     ap.add_argument("--no-c2", action="store_true", help="skip the extra C2 (configs[1]) measurement")
     ap.add_argument("--no-c5", action="store_true", help="skip the extra C5 (configs[4]'s workload on one GPU) measurement")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (N = 1, full workload) that measure `roofline.traffic` "
+                                                                  "on this box; the line then carries the committed passes' figure")
     ap.add_argument("--no-c1", action="store_true", help="skip the extra C1 (configs[0]: GPU next to the oracle's full CPU render) measurement")
     ap.add_argument("--dev", default="", help="development overrides, e.g. spectrum_samples=1,light_samples=0,bounces=2 (marks the line reduced)")
     ap.add_argument("--seed", type=int, default=1)
@@ -564,7 +624,11 @@ def main():
         launches = len(wl.launch_events)
         kernel_ms = sum(a.elapsed_time(b) for a, b in wl.launch_events) / max(args.steps, 1)
         counters = wl.counters_for_seeds(seeds_used)
-        line["roofline"] = wl.roofline(counters, kernel_ms, launches // max(args.steps, 1))
+        live = None
+        if world_size == 1 and not wl.reduced and not args.no_live_traffic and not force_native:
+            staged = wl.kernel_name().startswith("render_kernel_sm")
+            live = live_traffic(wl.name, args.seed, "render_kernel_sm<false" if staged else "render_kernel<false")
+        line["roofline"] = wl.roofline(counters, kernel_ms, launches // max(args.steps, 1), live)
         if world_size == 1 and not args.no_traversal:
             line["traversal_roofline"] = traversal_roofline(local_rank)
         if world_size == 1 and args.workload == "C3" and not args.no_c2 and not wl.reduced:
