@@ -394,6 +394,24 @@ typedef struct PyrBvhInfo {
 } PyrBvhInfo;
 int pyr_scene_bvh_info(PyrScene* scene, PyrBvhInfo* out);
 
+/* Introspection of the kernel a render of `scene` with `params` would run (nothing is launched; only spectrum_samples is read
+ * today). Results never depend on it -- every schedule is the same per-sample arithmetic as tracer.rs:208-345 -- but throughput
+ * does, and a maintainer wants to see why a scene is slow: */
+typedef struct PyrPathInfo {
+    uint32_t stage_scheduler; /* 0: the bounce-synchronous walk (scenes that live in LDS and run no interpreter programs); 1: the
+                                 stage-scheduled state machine */
+    uint32_t interpreter;     /* 1: some program of the scene is not a constant / spectrum / one of the fast shapes: the kernel
+                                 carries the program interpreter (and texture / normal-map sampling) */
+    uint32_t scene_in_lds;    /* 1: nodes and primitives are staged in LDS */
+    uint32_t tape;            /* 0: every wavelength's throughput is kept online; 1: spectral tape (no interpreter programs);
+                                 2: hit tape -- interpreter programs run once per hit, the per-wavelength part is replayed at
+                                 full width; needs spectrum_samples >= 4 and a tape form for every colour program (a product
+                                 of a mono texture and a spectrum has none) */
+    uint32_t phase_lanes;     /* lanes of a wave that must want a phase before it runs (stage scheduler; 0 otherwise) */
+    uint32_t reserved[3];
+} PyrPathInfo;
+int pyr_scene_path_info(PyrScene* scene, const PyrRenderParams* params, PyrPathInfo* out);
+
 /* ---------------------------------------------------------------- multi-GPU -----------
  * The reference is one process with shared memory; its unit of parallel work is the tile (renderer/simple.rs:36-55: every
  * tile has its own RNG and exposes its own pixels, renderer/mod.rs:125-189 hands tiles to worker threads). Here the scene

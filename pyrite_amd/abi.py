@@ -225,6 +225,17 @@ class PyrBvhInfo(C.Structure):
     ]
 
 
+class PyrPathInfo(C.Structure):
+    _fields_ = [
+        ("stage_scheduler", C.c_uint32),
+        ("interpreter", C.c_uint32),
+        ("scene_in_lds", C.c_uint32),
+        ("tape", C.c_uint32),
+        ("phase_lanes", C.c_uint32),
+        ("reserved", C.c_uint32 * 3),
+    ]
+
+
 class PyrDevelopParams(C.Structure):
     _fields_ = [
         ("step_size", C.c_float),
@@ -261,6 +272,7 @@ ENTRY_POINTS = {
     "pyr_scene_intersect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(PyrCounters)]),
     "pyr_scene_intersect_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pyr_scene_bvh_info": (C.c_int, [C.c_void_p, C.POINTER(PyrBvhInfo)]),
+    "pyr_scene_path_info": (C.c_int, [C.c_void_p, C.POINTER(PyrRenderParams), C.POINTER(PyrPathInfo)]),
     "pyr_film_blocks_grains": (C.c_uint64, [C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams)]),
     "pyr_film_blocks_assemble_device": (C.c_int, [C.POINTER(PyrFilmDesc), C.POINTER(PyrRenderParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pyr_comm_unique_id": (C.c_int, [C.c_void_p]),

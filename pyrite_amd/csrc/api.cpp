@@ -708,8 +708,8 @@ int reserve_tape(PyrScene* scene, RenderLaunch& L, hipStream_t stream) {
     return PYR_OK;
 }
 
-int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stream) {
-    if (L.chunk_end == L.chunk_begin) return PYR_OK;
+// Which schedule a render of this scene runs, and with which phase thresholds (defaults and the development switches).
+void choose_schedule(const PyrScene* scene, RenderLaunch& L) {
     const char* e = std::getenv("PYRITE_SCHEDULER");
     if (e && std::string(e) == "sm")
         L.scheduler = 1;
@@ -730,6 +730,11 @@ int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stre
     L.sm_trav_steps = steps && *steps ? (uint32_t)std::strtoul(steps, nullptr, 10) : 8u;
     const char* expose = std::getenv("PYRITE_SM_EXPOSE_LANES");
     L.sm_expose_lanes = expose && *expose ? (uint32_t)std::strtoul(expose, nullptr, 10) : L.sm_phase_lanes;
+}
+
+int render_batches(PyrScene* scene, RenderLaunch L, bool count, hipStream_t stream) {
+    if (L.chunk_end == L.chunk_begin) return PYR_OK;
+    choose_schedule(scene, L);
     if (L.scheduler != 0 && (scene->dev.needs_interpreter == 0 || uses_hit_tape(scene->dev, L))) {
         L.tape_lanes = tape_lanes_bound(scene->num_cus);
         L.tape_max_ops = tape_ops_bound(scene->dev, L);
@@ -1049,6 +1054,20 @@ int pyr_film_develop(const PyrFilmDesc* film, const PyrGrain* grains, const PyrD
     if ((rc = rgb_dev.alloc(pixels * 3)) != PYR_OK) return rc;
     if ((rc = develop_common(film, (const PyrGrain*)film_dev.ptr, params, (uint8_t*)rgb_dev.ptr, nullptr, true)) != PYR_OK) return rc;
     HIP_TRY(hipMemcpy(rgb_out, rgb_dev.ptr, pixels * 3, hipMemcpyDeviceToHost));
+    return PYR_OK;
+}
+
+int pyr_scene_path_info(PyrScene* scene, const PyrRenderParams* params, PyrPathInfo* out) {
+    if (!scene || !params || !out) return fail(PYR_ERR_INVALID_ARGUMENT, "null argument");
+    RenderLaunch L{};
+    L.spectrum_samples = params->spectrum_samples;
+    choose_schedule(scene, L);
+    *out = PyrPathInfo{};
+    out->stage_scheduler = L.scheduler;
+    out->interpreter = scene->dev.needs_interpreter;
+    out->scene_in_lds = scene_is_lds_resident(scene->dev) ? 1u : 0u;
+    out->tape = L.scheduler == 0 ? 0u : scene->dev.needs_interpreter == 0 ? 1u : uses_hit_tape(scene->dev, L) ? 2u : 0u;
+    out->phase_lanes = L.scheduler != 0 ? L.sm_phase_lanes : 0u;
     return PYR_OK;
 }
 

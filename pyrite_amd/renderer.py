@@ -113,6 +113,12 @@ class Renderer:
             share.apply(p)
         return p
 
+    def path_info(self, world: World, device=0):
+        """Which kernel a render of `world` with this renderer would run (pyr_scene_path_info): a dict of PyrPathInfo's fields."""
+        info, params = abi.PyrPathInfo(), self.params()
+        check(lib().pyr_scene_path_info(world.scene(device), C.byref(params), C.byref(info)))
+        return {name: int(getattr(info, name)) for name, _ in info._fields_ if name != "reserved"}
+
     def render(self, film: Film, camera: Camera, world: World, on_status=None, device=0, counters=False, tile_range=None, film_rows=None,
                window=None, share=None):
         """Blocking render into a host Film (adds to it). Returns the PyrCounters dict when counters=True.

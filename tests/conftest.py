@@ -33,4 +33,6 @@ def pytest_sessionfinish(session, exitstatus):
     out_dir = os.path.join(ROOT, "gpurun_out")
     if observed and os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "parity_observed.json"), "w") as f:
-            json.dump({"max_rel_l2": max(observed.values()), "tests": len(observed), "per_test": dict(sorted(observed.items()))}, f, indent=1)
+            json.dump({"max_rel_l2": max(observed.values()), "tests": len(observed),
+                       "fuzz_scenes_by_kernel_form": getattr(sys.modules.get("test_gpu_fuzz"), "KERNEL_FORMS", None) or None,
+                       "per_test": dict(sorted(observed.items()))}, f, indent=1)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "pyrite_gpu.h")
 
 STRUCTS = ["PyrGrain", "PyrFilmDesc", "PyrRenderParams", "PyrCamera", "PyrOperand", "PyrInstr", "PyrProgram", "PyrSpectrum", "PyrComponent",
-           "PyrMaterial", "PyrLamp", "PyrTexture", "PyrSceneDesc", "PyrCounters", "PyrHit", "PyrBvhInfo", "PyrDevelopParams"]
+           "PyrMaterial", "PyrLamp", "PyrTexture", "PyrSceneDesc", "PyrCounters", "PyrHit", "PyrBvhInfo", "PyrPathInfo", "PyrDevelopParams"]
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +48,7 @@ def test_errors_are_reported_not_aborted(lib):
     assert rc == abi.PYR_ERR_INVALID_ARGUMENT
     assert b"null" in lib.pyr_last_error()
     assert lib.pyr_scene_bvh_info(None, None) == abi.PYR_ERR_INVALID_ARGUMENT
+    assert lib.pyr_scene_path_info(None, None, None) == abi.PYR_ERR_INVALID_ARGUMENT
     lib.pyr_scene_destroy(None)  # must be a no-op
 
 

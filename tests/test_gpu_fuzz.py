@@ -119,6 +119,8 @@ def random_project(seed):
 # Seeds that once found something, always run: 37 (round 3) -- two wavelengths per sample and a tree four levels deep put the
 # staged scene where a store meant for the tape's value rows landed in builds without a tape (render_kernel_sm).
 REGRESSION_SEEDS = [37]
+KERNEL_FORMS = {}  # how many of them took which form (written out by conftest.py)
+PATHS_TAKEN = {}  # seed -> PyrPathInfo of the scene as the library would render it by default
 # Long campaigns: PYRITE_FUZZ_SEEDS=N runs N seeds of each kind, PYRITE_FUZZ_BASE=B starts them at B (another campaign, other scenes).
 FUZZ_BASE = int(__import__("os").environ.get("PYRITE_FUZZ_BASE", "0"))
 SCENE_SEEDS = sorted(set(range(FUZZ_BASE, FUZZ_BASE + int(__import__("os").environ.get("PYRITE_FUZZ_SEEDS", "200")))) | set(REGRESSION_SEEDS))
@@ -133,6 +135,7 @@ def test_random_scene_matches_the_oracle_on_every_scheduler(seed, gpu_lib, monke
     cfilm = r.new_film(width, height)
     ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
     assert np.isfinite(cfilm.grains).all()
+    PATHS_TAKEN[seed] = r.path_info(world)
     for scheduler in ("sync", "sm"):
         monkeypatch.setenv("PYRITE_SCHEDULER", scheduler)
         gfilm = r.new_film(width, height)
@@ -140,6 +143,21 @@ def test_random_scene_matches_the_oracle_on_every_scheduler(seed, gpu_lib, monke
         assert_parity(gfilm, cfilm)
         for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
             assert gcount[key] == ccount[key], (scheduler, key)
+
+
+@pytest.mark.gpu
+def test_the_random_scenes_reach_every_kernel_form(gpu_lib):
+    """The campaign above is only worth what it reaches: of the scenes it rendered, some ran the hit tape (round 4: interpreter
+    programs replayed at full width), some kept every wavelength online (a colour program without a tape form, or fewer than
+    four wavelengths), some had their scene in LDS. pyr_scene_path_info says which."""
+    if len(PATHS_TAKEN) < 50:
+        pytest.skip("needs the scene campaign of this module (at least 50 scenes) to have run in this process")
+    taken = list(PATHS_TAKEN.values())
+    hit_tape = sum(1 for p in taken if p["tape"] == 2)
+    online = sum(1 for p in taken if p["tape"] == 0 and p["interpreter"])
+    in_lds = sum(1 for p in taken if p["scene_in_lds"])
+    KERNEL_FORMS.update({"scenes": len(taken), "hit_tape": hit_tape, "interpreter_online": online, "scene_in_lds": in_lds})
+    assert hit_tape >= len(taken) // 10 and online >= len(taken) // 10 and in_lds >= len(taken) // 10, KERNEL_FORMS
 
 
 def test_random_projects_are_valid_on_the_cpu():

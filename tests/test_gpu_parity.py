@@ -151,6 +151,10 @@ def test_interpreter_scenes_with_and_without_the_hit_tape(name, hit_tape, gpu_li
 
     monkeypatch.setenv("PYRITE_HIT_TAPE", hit_tape)
     project, eligible = HIT_TAPE_CASES[name]
+    world, _, r, _ = scenes.build(project(), seed=11)
+    info = r.path_info(world)  # pyr_scene_path_info: what a render of this scene runs
+    world.close()
+    assert info["interpreter"] == 1 and info["stage_scheduler"] == 1 and info["tape"] == (2 if hit_tape == "1" and eligible else 0), info
     gfilm, cfilm, gcount, ccount = render_both(project(), 11, gpu_lib)
     assert_parity(gfilm, cfilm)
     for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
