@@ -344,6 +344,33 @@ def test_c3_shaped_scene_at_scale_50(glass, gpu_lib):
         assert gcount["exposures"] < gcount["samples"] * 10  # dispersed paths expose the hero wavelength only
 
 
+@pytest.mark.parametrize("hit_tape", ["1", "0"])
+@pytest.mark.parametrize("glassy", [False, True])
+def test_interpreter_material_on_a_mesh_that_does_not_live_in_lds(glassy, hit_tape, gpu_lib, monkeypatch):
+    """The interpreter builds of the stage scheduler on a scene walked from HBM (the form a textured production mesh takes: C3's box
+    with a 9,216-triangle knot): a fresnel mix of a mirror and an rgb()-coloured coat, or of dispersive glass and the coat (hero-only
+    paths beside full ones on one tape), with the hit tape and with every wavelength online -- both the oracle's film."""
+    from pyrite_amd.project import fresnel, material, mix, rgb
+    from pyrite_amd.renderer import Camera, Renderer, World
+
+    monkeypatch.setenv("PYRITE_HIT_TAPE", hit_tape)
+    coat = material.diffuse(color=rgb(0.8, 0.45, 0.2))
+    under = material.refractive(ior=1.5, dispersion=0.01371, color=1) if glassy else material.mirror(color=1)
+    mesh_material = {"surface": mix(under, coat, fresnel(1.5))}
+    project = scenes.c3_mesh_in_box(width=64, height=36, pixel_samples=4, bounces=12 if glassy else None, mesh_material=mesh_material)
+    world = World(scenes.c3_flat(segments=96, sides=48, mesh_material=mesh_material))
+    r = Renderer.from_project(project["renderer"], seed=4)
+    info = r.path_info(world)
+    assert info == {"stage_scheduler": 1, "interpreter": 1, "scene_in_lds": 0, "tape": 2 if hit_tape == "1" else 0, "phase_lanes": 32}, info
+    cam = Camera.from_project(project["camera"])
+    gfilm, cfilm = r.new_film(64, 36), r.new_film(64, 36)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    gcount = r.render(gfilm, cam, world, counters=True)
+    assert_parity(gfilm, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+
+
 def test_stage_scheduler_on_an_lds_resident_scene_with_a_one_level_lds_stack(gpu_lib, monkeypatch):
     """the kernels built for scenes staged in LDS have no scratch part of the traversal stack (one entry), so the
     launcher must keep the WHOLE stack in LDS for such scenes whatever PYRITE_LDS_STACK or the budget say -- also when the
