@@ -249,7 +249,7 @@ TRAFFIC_FORMULA = ("(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled p
                    "64 B); WRITE_SIZE is exact for float atomics; Infinity-Cache hits are counted (the counters sit at the L2's fabric side)")
 
 
-def live_traffic(workload, seed, kernel_part, pass_seconds=300):
+def live_traffic(workload, seed, kernel_part, pass_seconds=150):
     """PMC traffic of THIS build on THIS box: two child runs of this file's one launch under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes, no trace domain beside them, the program itself behind `--`; MI355X_MICROARCH.md "HBM").
     -> (bytes per launch, a description) or (None, why not). The children are ordinary child processes; the parent's scene
@@ -257,6 +257,7 @@ def live_traffic(workload, seed, kernel_part, pass_seconds=300):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
 
@@ -271,9 +272,16 @@ def live_traffic(workload, seed, kernel_part, pass_seconds=300):
                "--workload", workload, "--steps", "1", "--warmup", "0", "--seed", str(seed), "--no-cpu-baseline", "--no-traversal", "--no-c2", "--no-c5",
                "--no-c1", "--no-live-traffic"]
         try:
-            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=pass_seconds)
-            if done.returncode != 0:
-                return None, "the %s pass ended with code %d: %s" % (counter, done.returncode, done.stdout.decode(errors="replace")[-200:])
+            # a process group of its own: a pass that outlives its limit is ended together with the program it profiles
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                output, _ = child.communicate(timeout=pass_seconds)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, signal.SIGKILL)
+                child.communicate()
+                raise
+            if child.returncode != 0:
+                return None, "the %s pass ended with code %d: %s" % (counter, child.returncode, output.decode(errors="replace")[-200:])
             values = []
             for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
