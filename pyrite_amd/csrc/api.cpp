@@ -461,6 +461,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     if ((rc = s->plane_frames.upload(plane_frames.data(), plane_frames.size() * 4))) return rc;
     if ((rc = s->textures.upload(textures.data(), textures.size() * sizeof(DevTexture)))) return rc;
     if ((rc = s->texture_data.upload(d->texture_data, d->num_textures ? (size_t)d->num_texture_floats * 4 : 0))) return rc;
+    // the traversal addresses a node by a 32-bit byte offset from the tree's base (one SGPR pair + one VGPR per load): 4 GB of 64-byte
+    // binary nodes, 4 GB of 128-byte wide nodes -- about 200 M triangles, beyond which the call says so instead of wrapping around
+    if (bvh.nodes.size() >= (1ull << 26)) return fail(PYR_ERR_UNSUPPORTED, "scene too large: the acceleration structure has 2^26 nodes or more (4 GB)");
     if ((rc = s->nodes.upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64)))) return rc;
     // scenes that do not live in LDS also get the 4-wide tree for the resumable traversal (latency bound there);
     // PYRITE_WIDE_BVH=0 keeps the binary tree (A/B)
@@ -469,7 +472,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     const bool want_wide = (size_t)bvh.nodes.size() * 64 + prims.size() * 48 > 8 * 1024 && !(wide_env && wide_env[0] == '0');
     if (want_wide) {
         wide = collapse_to_wide(bvh);
-        if (wide.stack_need > kMaxStackDepth) wide = WideBvh{};
+        if (wide.stack_need > kMaxStackDepth || wide.nodes.size() >= (1ull << 25)) wide = WideBvh{}; // too deep, or past 4 GB: the binary tree
     }
     // Triangle pairs for the wide tree's leaves (device_scene.h DevPrimPair): every leaf gets ceil(n / 2) records of its own and
     // its code in the wide nodes is rewritten to count in records. PYRITE_PAIR_PRIMS=0 keeps the one-primitive records (A/B).
@@ -677,6 +680,12 @@ int check_render_args(PyrScene* scene, const PyrCamera* camera, const PyrFilmDes
     uint32_t rows = p->film_row_count ? p->film_row_count : film->height;
     if ((uint64_t)p->film_row_begin + rows > film->height) return fail(PYR_ERR_INVALID_ARGUMENT, "film window exceeds the image");
     if (p->spectrum_samples > 64) return fail(PYR_ERR_UNSUPPORTED, "spectrum_samples > 64");
+    // a pixel is a 32-bit index into the call's film buffer (0xFFFFFFFF stands for "none"): 65,535 x 65,535 still fits
+    if ((uint64_t)film->width * film->height >= 0xFFFFFFFFull) return fail(PYR_ERR_UNSUPPORTED, "image too large: 2^32 pixels or more");
+    if (p->film_layout == PYR_FILM_TILE_BLOCKS) {
+        const uint64_t tiles = (uint64_t)((film->width + p->tile_size - 1) / p->tile_size) * ((film->height + p->tile_size - 1) / p->tile_size);
+        if (tiles * (p->tile_size + 2ull) * (p->tile_size + 2ull) >= 0xFFFFFFFFull) return fail(PYR_ERR_UNSUPPORTED, "image too large for a film of tile blocks");
+    }
     if (p->film_layout > PYR_FILM_TILE_BLOCKS) return fail(PYR_ERR_INVALID_ARGUMENT, "unknown film layout");
     if (p->film_layout == PYR_FILM_TILE_BLOCKS && (p->film_row_begin || p->film_row_count))
         return fail(PYR_ERR_INVALID_ARGUMENT, "a film of tile blocks has no row window");

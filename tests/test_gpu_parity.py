@@ -197,6 +197,36 @@ def test_world_without_objects_is_all_sky(scheduler, gpu_lib, monkeypatch):
     assert gfilm.grains[..., 0].sum() > 0
 
 
+def test_calls_the_kernels_cannot_index_are_refused_before_anything_runs(gpu_lib):
+    """Sizes the 32-bit indices of the kernels do not reach -- 2^32 pixels, a window outside the image, more than 64 wavelengths -- are
+    errors of the call (never a wrap-around on the device); the film pointer is not touched (it points at eight bytes here)."""
+    import ctypes as C
+
+    from pyrite_amd import abi
+    from pyrite_amd._lib import lib
+
+    world, cam, r, _ = scenes.build(scenes.c2_cornell(16, 16, 1), seed=1)
+    grain = (C.c_float * 2)()
+    no_progress = C.cast(None, abi.PyrProgressFn)
+
+    def call(width, height, **overrides):
+        params = r.params()
+        for key, value in overrides.items():
+            setattr(params, key, value)
+        desc = abi.PyrFilmDesc(width, height, r.spectrum_bins, r.spectrum_span[0], r.spectrum_span[1] - r.spectrum_span[0])
+        rc = lib().pyr_render_simple(world.scene(0), C.byref(cam.c), C.byref(desc), C.byref(params), C.cast(grain, C.c_void_p), no_progress, None)
+        return rc, lib().pyr_last_error().decode()
+
+    assert call(65536, 65536) == (abi.PYR_ERR_UNSUPPORTED, "image too large: 2^32 pixels or more")
+    rc, message = call(60000, 60000, tile_size=8, film_layout=abi.PYR_FILM_TILE_BLOCKS)
+    assert rc == abi.PYR_ERR_UNSUPPORTED and "tile blocks" in message
+    assert call(16, 16, spectrum_samples=65)[0] == abi.PYR_ERR_UNSUPPORTED
+    assert call(16, 16, film_row_begin=8, film_row_count=9) == (abi.PYR_ERR_INVALID_ARGUMENT, "film window exceeds the image")
+    assert call(0, 16)[0] == abi.PYR_ERR_INVALID_ARGUMENT
+    assert grain[0] == 0.0 and grain[1] == 0.0
+    world.close()
+
+
 def test_empty_work_is_a_no_op(gpu_lib):
     world, cam, r, film = scenes.build(scenes.c2_cornell(16, 16, 0), seed=1)  # zero samples per pixel
     r.render(film, cam, world)
