@@ -347,7 +347,11 @@ const char* pyr_last_error(void);
 
 /* Replaces the part of World::from_project that builds the acceleration structure
  * (Bvh::new, world.rs:262 / spatial/bvh.rs:13-155) and freezes the scene: copies the description, builds the
- * BVH on the host, uploads everything to `device`. */
+ * BVH on the host, uploads everything to `device`.
+ *   Sizes: fewer than 2^28 triangles + spheres; the kernels address a node by a 32-bit byte offset, so an acceleration
+ * structure of 4 GB (2^26 binary nodes, about 200 M triangles) or more is refused with PYR_ERR_UNSUPPORTED rather than
+ * wrapped around. A render call takes fewer than 2^32 pixels (and, as tile blocks, fewer than 2^32 block pixels), at most
+ * 64 wavelengths per sample and fewer than 2^32 chunks of 64 samples; larger calls are refused the same way. */
 int pyr_scene_create(const PyrSceneDesc* desc, int device, PyrScene** out_scene);
 void pyr_scene_destroy(PyrScene* scene);
 
