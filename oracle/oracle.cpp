@@ -1401,6 +1401,8 @@ struct Bounce { // tracer.rs:157-167
     uint32_t light_first = 0, light_count = 0;
 };
 
+static thread_local bool g_debug_shadow_rays = false; // developer aid (ORACLE_DEBUG_PIXEL): set around the traced sample
+
 // trace_direct, tracer.rs:347-442. The reference panics in pick_lamp's gen_range(0..0) when the world has no
 // lamps; this restatement returns no direct light (and draws nothing) in that case.
 void trace_direct(const OracleScene& s, Rng& rng, uint32_t samples, float wavelength, V3 ray_in, V3 position, V3 normal, Exe& exe,
@@ -1430,6 +1432,9 @@ void trace_direct(const OracleScene& s, Rng& rng, uint32_t samples, float wavele
                 blocked = false;
             else
                 blocked = true;
+            if (g_debug_shadow_rays)
+                std::fprintf(stderr, "[shadow] origin (%.9g %.9g %.9g) direction (%.9g %.9g %.9g) hit %d distance %.9g limit %.9g blocked %d\n", position.x, position.y, position.z,
+                             ls.direction.x, ls.direction.y, ls.direction.z, (int)has_hit, has_hit ? hit.distance : 0.0f, ls.has_sq_distance ? ls.sq_distance - DIST_EPSILON : -1.0f, (int)blocked);
             if (!blocked) {
                 DirectLight dl{};
                 float material_probability;
@@ -1807,7 +1812,13 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
         float wavelength = main_sample.wavelength;
 
         const Ray camera_ray = ray;
+        if (dbg) { // the sample's shadow rays are printed as they are traced (trace_direct), blocked ones too
+            unsigned dx = 0, dy = 0;
+            uint64_t qx, qy;
+            g_debug_shadow_rays = std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy;
+        }
         trace(s, path, lights, rng, ray, wavelength, p.bounces, p.light_samples, exe, c);
+        g_debug_shadow_rays = false;
 
         bool use_additional = true;
         for (const Bounce& bounce : path) {

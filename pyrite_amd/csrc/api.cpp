@@ -615,6 +615,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         v.hit_tape = ok ? 1u : 0u;
         if (!ok) v.rgb_records = 0u;
     }
+    v.shadow_margin = d->num_spheres != 0 ? 1.01f : 1.001f; // device_scene.h
     v.hero_only_records = 0;
     for (uint32_t i = 0; i < d->num_materials; ++i)
         for (uint32_t k = 0; k < d->materials[i].num_emissive; ++k) {

@@ -134,6 +134,11 @@ struct DevScene {
     // for this scene too and the interpreter runs once per hit instead of once per hit and wavelength
     uint32_t hit_tape;
     uint32_t rgb_records; // some colour program is HIT_RGB: its contributions are four records (three coefficients + the factor)
+    // Boxes a shadow ray may skip lie beyond limit * shadow_margin (+ 1e-3), limit = the blocking limit (a squared distance): 1.001
+    // covers the ulps between a box's entry distance and a triangle's hit distance; scenes with spheres take 1.01 -- collision's
+    // sphere routine loses every digit of l.l - tca^2 for a ray that passes at a thousand radii or more and then reports hits up to a
+    // radius NEARER than the sphere's own box, which the reference, walking with closest = inf, still counts as blockers.
+    float shadow_margin;
 };
 
 constexpr uint32_t kMaxStackDepth = 64; // >= kMaxBvhDepth (bvh.h) and >= the wide tree's stack need (else the binary tree is walked)

@@ -801,7 +801,7 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
     }
     const f3 inv = box_reciprocal(d);
     const uint32_t sign_x = binary_sign_offset(d.x), sign_y = binary_sign_offset(d.y), sign_z = binary_sign_offset(d.z);
-    const float limit_cull = limit * 1.001f + 1.0e-3f; // +inf stays +inf
+    const float limit_cull = limit * S.shadow_margin + 1.0e-3f; // +inf stays +inf
     int sp = 0;
     int node = 0;
     // Every turn of the loop is one inner-node visit or ONE primitive of a leaf (the leaf code in `node` shrinks), so lanes at
@@ -817,7 +817,7 @@ DEV bool traverse(const DevScene& S, const float4* nodes, const float4* prims, f
             if (SHADOW) {
                 // A box can be skipped only if nothing in it can block. Its computed entry distance and a primitive's computed
                 // hit distance are independent roundings of (at best) the same number -- for a zero-thickness box they differ
-                // by ulps either way -- so the cut-off keeps a 0.1 % margin over the blocking limit instead of comparing against
+                // by ulps either way -- so the cut-off keeps a margin over the blocking limit (DevScene::shadow_margin: 0.1 %, 1 % where spheres are) instead of comparing against
                 // it exactly (found on C3: at scene scale 50, d^2 ~ 2500 has an ulp of 2.4e-4 > DIST_EPSILON and an exact
                 // comparison skipped lamp triangles the reference tests).
                 h0 = e0 >= 0.0f && e0 * e0 < limit_cull;
@@ -1799,7 +1799,7 @@ struct Trav { // resumable World::intersect
     // about to be stepped (trav_ray_signs); the straight-line step loads near and far planes directly (wide_node_children).
     uint32_t nx = 0, ny = 0, nz = 0;
     // `closest` is the distance boxes are cut off at: the closest hit so far for an extension ray; for a shadow ray the square
-    // root of the blocking limit with its 0.1 % margin (traverse<>'s limit_cull) -- one comparison serves both kinds of ray, and
+    // root of the blocking limit with its margin (traverse<>'s limit_cull, DevScene::shadow_margin) -- one comparison serves both kinds of ray, and
     // the half-ulp of the root is far inside that margin. A shadow ray never reads it as a hit distance.
     float limit, closest;
     int node, sp;
@@ -1814,12 +1814,12 @@ DEV void trav_ray_signs(Trav& t) {
     t.nz = (__float_as_uint(t.d.z) >> 31) * 48u;
 }
 // Puts a query whose ray, limit and plane results are set at the root of the tree.
-// v_sqrt_f32 alone: the ulp it may be off by is far inside the 0.1 % margin. +inf stays +inf; a negative limit gives NaN: nothing passes
-DEV float shadow_cutoff(float limit) { return __builtin_amdgcn_sqrtf(limit * 1.001f + 1.0e-3f); }
+// v_sqrt_f32 alone: the ulp it may be off by is far inside the margin (0.1 % at least). +inf stays +inf; a negative limit gives NaN: nothing passes
+DEV float shadow_cutoff(float limit, float margin) { return __builtin_amdgcn_sqrtf(limit * margin + 1.0e-3f); }
 // (t.inv is NOT set here: the kernels compute it where a ray is about to be stepped -- the stage scheduler at every entry of
 // its traversal phase -- so that the three registers are free while the other phases run.)
-DEV void trav_restart(Trav& t) {
-    if (t.shadow) t.closest = shadow_cutoff(t.limit);
+DEV void trav_restart(Trav& t, float shadow_margin) {
+    if (t.shadow) t.closest = shadow_cutoff(t.limit, shadow_margin);
     t.blocked = false;
     t.node = 0;
     t.sp = 0;
@@ -1853,7 +1853,7 @@ DEV bool trav_begin(const DevScene& S, Trav& t, f3 o, f3 d, bool shadow, float l
             }
         }
     }
-    trav_restart(t);
+    trav_restart(t, S.shadow_margin);
     return false;
 }
 
@@ -2005,11 +2005,11 @@ DEV bool leaf_prim_test(const float4 a, const float4 b, const float4 c, Trav& t,
     }
     // the verdict as selects (world.rs:290 for an extension ray, tracer.rs:381-389 for a shadow ray), then where to go next
     ok = ok & (dist > DIST_EPSILON);
-    // No ray kind in here: an extension ray's limit is -inf (trav_begin). A shadow ray may take a hit as its `closest` too --
-    // one in the 0.1 % margin beyond the limit, nearer than the cut-off: every blocker is nearer still (its distance squared is
-    // below the limit), so its boxes stay inside the tighter cut-off; the hit itself is read by nobody.
+    // An extension ray's limit is -inf (trav_begin): nothing blocks it. A shadow ray keeps its cut-off (trav_restart) whatever it
+    // meets beyond the limit: where spheres are, a blocker's own box may lie BEYOND the lamp's hit (DevScene::shadow_margin), and the
+    // reference -- a closest-hit walk from closest = inf -- counts such a blocker (fuzz scene 11941, tools/fuzz_trace.py).
     const bool blocks = ok & (dist * dist < t.limit);
-    const bool closer = ok & (dist < t.closest);
+    const bool closer = ok & (dist < t.closest) & !t.shadow;
     t.blocked = t.blocked | blocks;
     t.closest = closer ? dist : t.closest;
     t.shape = closer ? shape : t.shape;

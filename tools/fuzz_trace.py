@@ -81,7 +81,43 @@ for block in text.split("[oracle] tile")[1:]:
             if np.isfinite(pos).all():  # the shadow rays the oracle found unblocked (blocked ones are not kept by trace_direct)
                 rays.append(pos + [float(v) for v in m.groups()[1:]])
                 tags.append((head, "bounce %d light %d (unblocked in the oracle)" % (k, j)))
+# every shadow ray of the pixel's samples as the oracle traced it, blocked ones too (oracle.cpp trace_direct prints them)
+shadow = re.findall(r"\[shadow\] origin \(%s %s %s\) direction \(%s %s %s\) hit (\d) distance %s limit %s blocked (\d)" % ((num,) * 6 + (num, num)), text)
+for m in shadow:
+    rays.append([float(v) for v in m[:6]])
+    tags.append(("shadow ray", "oracle: hit %s at %s, limit %s, blocked %s" % (m[6], m[7], m[8], m[9])))
 print("pixel", pixel, ":", len(text.split("[oracle] tile")) - 1, "samples,", len(rays), "rays")
+
+
+def inconsistent_spheres(ray):
+    """Spheres whose intersection routine (collision's, shapes/mod.rs:57-74, in f32 as both sides compute it) reports a hit NEARER than
+    the entry of the sphere's own bounding box (math.rs:184-207): l.l - tca^2 has lost its digits (a ray passing thousands of radii
+    away). The reference only tests a shape whose box is entered before the closest hit so far (spatial/bvh.rs:201-230), so whether
+    such a hit counts depends on the ORDER in which its tree is walked -- the answer is the reference's tree's, not the scene's."""
+    f32 = np.float32
+    o, d = ray[:3].astype(f32), ray[3:].astype(f32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = (f32(1) / d).astype(f32)
+        found = []
+        for i, (cx, cy, cz, rad) in enumerate(np.asarray(world.flat.spheres, dtype=f32).reshape(-1, 4)):
+            c = np.array([cx, cy, cz], dtype=f32)
+            tmin, tmax = f32(-np.inf), f32(np.inf)
+            for k in range(3):
+                t1, t2 = f32(f32(c[k] - rad - o[k]) * inv[k]), f32(f32(c[k] + rad - o[k]) * inv[k])
+                tmin, tmax = np.fmax(tmin, np.fmin(t1, t2)), np.fmin(tmax, np.fmax(t1, t2))
+            if not (tmax >= tmin and tmax >= 0):
+                continue
+            l = (c - o).astype(f32)
+            ll = f32(f32(f32(l[0] * l[0]) + f32(l[1] * l[1])) + f32(l[2] * l[2]))
+            tca = f32(f32(f32(l[0] * d[0]) + f32(l[1] * d[1])) + f32(l[2] * d[2]))
+            d2 = f32(ll - f32(tca * tca))
+            r2 = f32(rad * rad)
+            if tca < 0 or d2 > r2:
+                continue
+            near = f32(tca - np.sqrt(f32(r2 - d2)))
+            if near < max(tmin, f32(0)):
+                found.append("sphere %d: routine says %.9g (l.l %.9g - tca^2 = %.9g against r^2 %.9g), its box is entered at %.9g" % (i, near, ll, d2, r2, max(tmin, f32(0))))
+    return found
 verdict = "no ray of the oracle's paths is answered differently: the difference is in the shading arithmetic (or in a shadow ray)"
 if rays:
     rays = np.array(rays, dtype=np.float32)
@@ -90,8 +126,11 @@ if rays:
     for t, ray, a, b in zip(tags, rays, oh, gh):
         if a.tobytes() != b.tobytes():
             tie = float(a[0]) == float(b[0])
+            garbage = [] if tie else inconsistent_spheres(ray)
             print(t, "ray", ray, "\n   oracle", a, "\n   gpu   ", b, "   <-- " + ("TIE: same f32 distance, another primitive" if tie else "DIFFERENT"))
-            verdict = "tie" if tie else "DEFECT: the closest hit differs"
+            for line in garbage:
+                print("   " + line)
+            verdict = "tie" if tie else ("order-dependent in the reference: a sphere hit nearer than its own box's entry" if garbage else "DEFECT: the closest hit differs")
             break
 print("verdict:", verdict)
 if verdict.startswith("no ray"):
