@@ -27,7 +27,9 @@ def assert_parity(gpu_film, cpu_film):
     assert not np.isnan(gpu_film.grains).any()
 
 
-def random_project(seed):
+def random_project(seed, mesh=False):
+    """mesh=True: no spheres; a torus knot of 800-4,000 triangles with per-vertex texture coordinates and a random material instead -- a
+    triangle-only scene that does not fit LDS, i.e. the tree of triangle pairs the BASELINE meshes walk, under interpreter programs."""
     rng = np.random.default_rng(seed)
     tex = scenes._generated_textures(seed=seed, size=8)
 
@@ -74,7 +76,15 @@ def random_project(seed):
     if rng.random() < 0.7:
         objects.append(shape.plane(origin=vector(0, 0, float(rng.uniform(-0.2, 0.2))), normal=vector(float(rng.uniform(-0.1, 0.1)), 0, 1), material=mat(),
                                    texture_scale=vector(float(rng.uniform(0.5, 3)), float(rng.uniform(0.5, 3)))))
-    for _ in range(int(rng.integers(1, 5))):
+    if mesh:
+        tri, nrm = scenes.torus_knot_mesh(segments=int(rng.integers(40, 90)), sides=int(rng.integers(10, 24)), noise_seed=int(seed), fit_min=(-2.5, -2.0, 0.2), fit_max=(2.5, 2.0, 3.2))
+        n = len(tri)
+        uv = (tri.reshape(-1, 3)[:, :2] * f32(0.7) + tri.reshape(-1, 3)[:, 2:3] * f32(0.3)).astype(f32)
+        corner = np.arange(3 * n).reshape(n, 3)
+        knot = {"position": tri.reshape(-1, 3), "texture": uv, "normal": nrm.reshape(-1, 3),
+                "objects": [{"name": "knot", "polys": [[(int(a), int(a), int(a)), (int(b), int(b), int(b)), (int(c), int(c), int(c))] for a, b, c in corner]}]}
+        objects.append(shape.mesh(file=knot, materials={"knot": mat()}))
+    for _ in range(0 if mesh else int(rng.integers(1, 5))):
         r = float(rng.uniform(0.3, 1.0))
         objects.append(shape.sphere(position=vector(float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), r + float(rng.uniform(0, 1.5))), radius=r, material=mat(),
                                     texture_scale=vector(float(rng.uniform(0.2, 1)), float(rng.uniform(0.2, 1)))))
@@ -90,6 +100,8 @@ def random_project(seed):
         objects.append(shape.mesh(file=mesh, materials={"soup": mat()}, scale=float(rng.uniform(0.6, 1.2)), transform=xf))
     lamp_kinds = rng.permutation(4)[: int(rng.integers(1, 4))]
     for k in lamp_kinds:
+        if k == 0 and mesh:
+            k = 1  # a point light in the sphere lamp's place
         if k == 0:
             objects.append(shape.sphere(position=vector(float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), float(rng.uniform(2.5, 4))), radius=float(rng.uniform(0.2, 0.6)),
                                         material={"surface": material.emissive(color=light_source.d65 * float(rng.uniform(4, 12)))}))
@@ -123,6 +135,7 @@ def random_project(seed):
 # lamp nearer than the lamp's own box and inside the blocking limit; the reference counts it, the kernels' cut-off skipped the box.
 REGRESSION_SEEDS = [37, 11941]
 KERNEL_FORMS = {}  # how many of them took which form (written out by conftest.py)
+MESH_PATHS_TAKEN = {}
 PATHS_TAKEN = {}  # seed -> PyrPathInfo of the scene as the library would render it by default
 # Long campaigns: PYRITE_FUZZ_SEEDS=N runs N seeds of each kind, PYRITE_FUZZ_BASE=B starts them at B (another campaign, other scenes).
 FUZZ_BASE = int(__import__("os").environ.get("PYRITE_FUZZ_BASE", "0"))
@@ -148,6 +161,31 @@ def test_random_scene_matches_the_oracle_on_every_scheduler(seed, gpu_lib, monke
             assert gcount[key] == ccount[key], (scheduler, key)
 
 
+MESH_SEEDS = range(FUZZ_BASE, FUZZ_BASE + int(__import__("os").environ.get("PYRITE_FUZZ_MESHES", "40")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", MESH_SEEDS)
+def test_random_mesh_scene_matches_the_oracle(seed, gpu_lib):
+    """The interpreter builds of the stage scheduler on the tree of triangle pairs (a scene walked from HBM): random materials -- textures,
+    normal maps, fresnel mixes, rgb() colours, dispersive glass -- on a knot mesh; hit tape or online as the colour programs allow."""
+    project = random_project(500000 + seed, mesh=True)
+    world, cam, r, _ = scenes.build(project, seed=seed)
+    width, height = project["image"]["width"], project["image"]["height"]
+    info = r.path_info(world)
+    assert info["scene_in_lds"] == 0 and info["stage_scheduler"] == 1, info
+    MESH_PATHS_TAKEN[seed] = info
+    cfilm = r.new_film(width, height)
+    ccount = oracle.OracleScene(world).render(r, cam, cfilm, threads=8)
+    assert np.isfinite(cfilm.grains).all()
+    gfilm = r.new_film(width, height)
+    gcount = r.render(gfilm, cam, world, counters=True)
+    assert_parity(gfilm, cfilm)
+    for key in ("samples", "extension_rays", "shadow_rays", "shaded_hits", "exposures"):
+        assert gcount[key] == ccount[key], key
+    world.close()
+
+
 @pytest.mark.gpu
 def test_the_random_scenes_reach_every_kernel_form(gpu_lib):
     """The campaign above is only worth what it reaches: of the scenes it rendered, some ran the hit tape (round 4: interpreter
@@ -159,7 +197,11 @@ def test_the_random_scenes_reach_every_kernel_form(gpu_lib):
     hit_tape = sum(1 for p in taken if p["tape"] == 2)
     online = sum(1 for p in taken if p["tape"] == 0 and p["interpreter"])
     in_lds = sum(1 for p in taken if p["scene_in_lds"])
-    KERNEL_FORMS.update({"scenes": len(taken), "hit_tape": hit_tape, "interpreter_online": online, "scene_in_lds": in_lds})
+    meshes = list(MESH_PATHS_TAKEN.values())
+    KERNEL_FORMS.update({"scenes": len(taken), "hit_tape": hit_tape, "interpreter_online": online, "scene_in_lds": in_lds, "mesh_scenes": len(meshes),
+                         "mesh_hit_tape": sum(1 for p in meshes if p["tape"] == 2), "mesh_interpreter_online": sum(1 for p in meshes if p["tape"] == 0 and p["interpreter"])})
+    if len(meshes) >= 20:
+        assert KERNEL_FORMS["mesh_hit_tape"] >= 2 and KERNEL_FORMS["mesh_interpreter_online"] >= 2, KERNEL_FORMS
     assert hit_tape >= len(taken) // 10 and online >= len(taken) // 10 and in_lds >= len(taken) // 10, KERNEL_FORMS
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): python tools/fuzz_trace.py scene|soup SEED [X Y] -- where does the GPU film of a fuzz case differ from
+"""Developer tool (GPU box): python tools/fuzz_trace.py scene|soup|mesh SEED [X Y] -- where does the GPU film of a fuzz case differ from
 the oracle's, and why? Finds the differing pixels (or takes one), prints the oracle's paths through the first of them
 (ORACLE_DEBUG_PIXEL) and walks the camera ray, every extension ray and every unblocked shadow ray of those paths through World::intersect on both sides:
 a film difference that starts at two primitives met at the same f32 distance is a tie, anything else is a defect.
@@ -22,8 +22,8 @@ from test_gpu_parity import rel_l2
 
 
 def build():
-    if kind == "scene":
-        project = random_project(1000 + seed)
+    if kind in ("scene", "mesh"):
+        project = random_project(500000 + seed, mesh=True) if kind == "mesh" else random_project(1000 + seed)
         world, cam, r, _ = scenes.build(project, seed=seed)
         return world, cam, r, project["image"]["width"], project["image"]["height"]
     world = World(random_soup(2000 + seed))
