@@ -264,6 +264,10 @@ def live_traffic(workload, seed, kernel_part, pass_seconds=150):
     rocprof = shutil.which("rocprofv3")
     if rocprof is None:
         return None, "rocprofv3 is not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        # a profiler's library already sits in this process: a second one under it would start from a process that has
+        # initialised the GPU before its own program is in place
+        return None, "this run is itself being profiled"
     env = dict(os.environ, TMPDIR="/tmp")
     kb, kernel, t0 = {}, None, time.time()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -15,7 +15,7 @@ step() { # name, seconds, command...
   [ $rc -ne 0 ] && { echo "$name failed rc=$rc"; tail -n 5 $OUT/$name.log; }
   return 0
 }
-C3="--workload C3 --no-cpu-baseline --no-traversal --no-c2 --no-c5"
+C3="--workload C3 --no-cpu-baseline --no-traversal --no-c2 --no-c5 --no-c1 --no-live-traffic"
 PMC="--pmc"
 if [ "${ONLY:-all}" = "all" ] || [ "$ONLY" = "bench" ]; then
   T0=$(date +%s.%N)
@@ -38,15 +38,15 @@ if [ "${ONLY:-all}" = "all" ] || [ "$ONLY" = "isect" ]; then
   step isect_tcp 300 rocprofv3 $PMC TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $OUT/isect_tcp -o tcp -- python3 $R/tools/prof_intersect_c3.py
 fi
 if [ "${ONLY:-all}" = "all" ] || [ "$ONLY" = "c5" ]; then
-  step c5_bench 600 python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal
-  step c5_trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_trace -o c5 -- python3 $R/bench.py --workload C5 --spp 256 --steps 2 --warmup 0 --no-cpu-baseline --no-traversal
-  step c5_fetch 300 rocprofv3 $PMC FETCH_SIZE --output-format csv -d $OUT/c5_fetch -o fetch -- python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal
-  step c5_write 300 rocprofv3 $PMC WRITE_SIZE --output-format csv -d $OUT/c5_write -o write -- python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal
-  step c5_trace_full 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_trace_full -o c5 -- python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal
-  step c5_sq1 300 rocprofv3 $PMC SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/c5_sq1 -o sq -- python3 $R/bench.py --workload C5 --spp 32 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal
+  step c5_bench 600 python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal --no-live-traffic
+  step c5_trace 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_trace -o c5 -- python3 $R/bench.py --workload C5 --spp 256 --steps 2 --warmup 0 --no-cpu-baseline --no-traversal --no-live-traffic
+  step c5_fetch 300 rocprofv3 $PMC FETCH_SIZE --output-format csv -d $OUT/c5_fetch -o fetch -- python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal --no-live-traffic
+  step c5_write 300 rocprofv3 $PMC WRITE_SIZE --output-format csv -d $OUT/c5_write -o write -- python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal --no-live-traffic
+  step c5_trace_full 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_trace_full -o c5 -- python3 $R/bench.py --workload C5 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal --no-live-traffic
+  step c5_sq1 300 rocprofv3 $PMC SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/c5_sq1 -o sq -- python3 $R/bench.py --workload C5 --spp 32 --steps 1 --warmup 0 --no-cpu-baseline --no-traversal --no-live-traffic
 fi
 if [ "${ONLY:-all}" = "all" ] || [ "$ONLY" = "c2" ]; then
-  C2="--workload C2 --no-cpu-baseline --no-traversal"
+  C2="--workload C2 --no-cpu-baseline --no-traversal --no-live-traffic"
   step c2_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_trace -o c2 -- python3 $R/bench.py $C2 --steps 5 --warmup 1
   step c2_fetch 300 rocprofv3 $PMC FETCH_SIZE --output-format csv -d $OUT/c2_fetch -o fetch -- python3 $R/bench.py $C2 --steps 1 --warmup 0
   step c2_write 300 rocprofv3 $PMC WRITE_SIZE --output-format csv -d $OUT/c2_write -o write -- python3 $R/bench.py $C2 --steps 1 --warmup 0
