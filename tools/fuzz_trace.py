@@ -23,7 +23,7 @@ from test_gpu_parity import rel_l2
 
 def build():
     if kind in ("scene", "mesh"):
-        project = random_project(500000 + seed, mesh=True) if kind == "mesh" else random_project(1000 + seed)
+        project = random_project(500000 + seed, knot=True) if kind == "mesh" else random_project(1000 + seed)
         world, cam, r, _ = scenes.build(project, seed=seed)
         return world, cam, r, project["image"]["width"], project["image"]["height"]
     world = World(random_soup(2000 + seed))
