@@ -140,6 +140,7 @@ def random_project(seed, knot=False):
 # 11941 (round 4) -- a shadow ray from 688 units out on a plane towards a spherical lamp: the sphere routine, its digits gone, reports the
 # lamp nearer than the lamp's own box and inside the blocking limit; the reference counts it, the kernels' cut-off skipped the box.
 REGRESSION_SEEDS = [37, 11941]
+REGRESSION_OBJECT_COUNTS = [6, 5, 5]  # objects of scenes 37, 11941, 10912 as the campaigns generated them (test_the_generator_still_makes_...)
 KERNEL_FORMS = {}  # how many of them took which form (written out by conftest.py)
 MESH_PATHS_TAKEN = {}
 PATHS_TAKEN = {}  # seed -> PyrPathInfo of the scene as the library would render it by default
@@ -209,6 +210,16 @@ def test_the_random_scenes_reach_every_kernel_form(gpu_lib):
     if len(meshes) >= 20:
         assert KERNEL_FORMS["mesh_hit_tape"] >= 2 and KERNEL_FORMS["mesh_interpreter_online"] >= 2, KERNEL_FORMS
     assert hit_tape >= len(taken) // 10 and online >= len(taken) // 10 and in_lds >= len(taken) // 10, KERNEL_FORMS
+
+
+def test_the_generator_still_makes_the_scenes_the_campaigns_ran():
+    """The seeds are only worth keeping while the generator draws the same scenes from them: the regression scenes by their shape (a change
+    to random_project that moves one draw shows up here, on the CPU, and not as a regression seed that silently tests something else)."""
+    shapes = {seed: (p["image"]["width"], p["image"]["height"], repr(p["renderer"]), len(p["world"]["objects"])) for seed, p in ((s, random_project(1000 + s)) for s in (37, 11941, 10912))}
+    assert shapes[37] == (41, 28, "simple(pixel_samples=6, threads=None, bounces=2, light_samples=1, spectrum_samples=2, spectrum_resolution=None, tile_size=16, extra={})", shapes[37][3])
+    assert shapes[11941][:3] == (48, 31, "simple(pixel_samples=4, threads=None, bounces=9, light_samples=2, spectrum_samples=4, spectrum_resolution=None, tile_size=8, extra={})")
+    assert shapes[10912][:2] == (35, 16)
+    assert [shapes[s][3] for s in (37, 11941, 10912)] == REGRESSION_OBJECT_COUNTS
 
 
 def test_random_projects_are_valid_on_the_cpu():
