@@ -25,6 +25,9 @@ Extra objects on the line:
                 (FETCH_SIZE, WRITE_SIZE; ~25 s each), falling back to the passes committed under profiles/ when rocprofv3
                 is missing or --no-live-traffic is given (`traffic_source` says which); `measured_hbm_GBps` = traffic / kernel time, what the fabric really moved. `bytes_per_sample` is
                 printed because the algorithmic figure rewards wasted tests: a better tree lowers both it and `achieved`.
+  issue         (N = 1, full workload, with the PMC passes) what binds the kernel when it is not HBM: `valu_busy`, the share of the time the
+                vector ALUs execute an instruction, and `lane_occupancy`, the active lanes per vector instruction / 64, from one more PMC pass
+                (SQ counters) of a 32-spp launch of the same kernel in this run.
   c2            (N = 1, default workload only) configs[1], the 36-triangle Cornell box at 1024^2 x 256 spp, three steps: its
                 scene lives in LDS, so its algorithmic bytes are LDS reads and the object says "bound": "lds".
   c5            (N = 1, default workload only) configs[4]'s workload on one GPU: the same mesh made of dispersive glass, 20
@@ -249,11 +252,11 @@ TRAFFIC_FORMULA = ("(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled p
                    "64 B); WRITE_SIZE is exact for float atomics; Infinity-Cache hits are counted (the counters sit at the L2's fabric side)")
 
 
-def live_traffic(workload, seed, kernel_part, pass_seconds=150):
-    """PMC traffic of THIS build on THIS box: two child runs of this file's one launch under `rocprofv3 --pmc` (FETCH_SIZE and
-    WRITE_SIZE in separate passes, no trace domain beside them, the program itself behind `--`; MI355X_MICROARCH.md "HBM").
-    -> (bytes per launch, a description) or (None, why not). The children are ordinary child processes; the parent's scene
-    stays where it is (a few GB of 288)."""
+def pmc_pass(workload, seed, kernel_part, counters, extra_args=(), pass_seconds=150):
+    """One child run of this file's one launch under `rocprofv3 --pmc <counters>` (no trace domain beside them, the program itself
+    behind `--`) -> ({counter: mean over the launches of the kernel whose name contains kernel_part}, the kernel's name), or
+    (None, why not). The child is an ordinary child process in a process group of its own: a pass that outlives its limit is ended
+    together with the program it profiles. The parent's scene stays where it is (a few GB of 288)."""
     import csv
     import glob
     import shutil
@@ -268,42 +271,72 @@ def live_traffic(workload, seed, kernel_part, pass_seconds=150):
         # a profiler's library already sits in this process: a second one under it would start from a process that has
         # initialised the GPU before its own program is in place
         return None, "this run is itself being profiled"
-    env = dict(os.environ, TMPDIR="/tmp")
+    out = tempfile.mkdtemp(prefix="pyr_pmc_", dir="/tmp")
+    cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+           "--workload", workload, "--steps", "1", "--warmup", "0", "--seed", str(seed), "--no-cpu-baseline", "--no-traversal", "--no-c2", "--no-c5",
+           "--no-c1", "--no-live-traffic", *extra_args]
+    try:
+        child = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            output, _ = child.communicate(timeout=pass_seconds)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)
+            child.communicate()
+            return None, "the %s pass took more than %d s" % ("/".join(counters), pass_seconds)
+        if child.returncode != 0:
+            return None, "the %s pass ended with code %d: %s" % ("/".join(counters), child.returncode, output.decode(errors="replace")[-200:])
+        values, kernel = {}, None
+        for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if kernel_part in row["Kernel_Name"] and row["Counter_Name"] in counters:
+                        values.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                        kernel = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        missing = [c for c in counters if c not in values]
+        if missing:
+            return None, "the pass has no %s row of %s" % ("/".join(missing), kernel_part)
+        return {c: sum(v) / len(v) for c, v in values.items()}, kernel
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def live_traffic(workload, seed, kernel_part):
+    """PMC traffic of THIS build on THIS box: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md "HBM")
+    -> (bytes per launch, a description) or (None, why not)."""
     kb, kernel, t0 = {}, None, time.time()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out = tempfile.mkdtemp(prefix="pyr_pmc_", dir="/tmp")
-        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--workload", workload, "--steps", "1", "--warmup", "0", "--seed", str(seed), "--no-cpu-baseline", "--no-traversal", "--no-c2", "--no-c5",
-               "--no-c1", "--no-live-traffic"]
-        try:
-            # a process group of its own: a pass that outlives its limit is ended together with the program it profiles
-            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
-            try:
-                output, _ = child.communicate(timeout=pass_seconds)
-            except subprocess.TimeoutExpired:
-                os.killpg(child.pid, signal.SIGKILL)
-                child.communicate()
-                raise
-            if child.returncode != 0:
-                return None, "the %s pass ended with code %d: %s" % (counter, child.returncode, output.decode(errors="replace")[-200:])
-            values = []
-            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if kernel_part in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            values.append(float(row["Counter_Value"]))
-                            kernel = row["Kernel_Name"].split("(")[0].replace("void ", "")
-            if not values:
-                return None, "the %s pass has no row of %s" % (counter, kernel_part)
-            kb[counter] = sum(values) / len(values)
-        except subprocess.TimeoutExpired:
-            return None, "the %s pass took more than %d s" % (counter, pass_seconds)
-        finally:
-            shutil.rmtree(out, ignore_errors=True)
+        got, kernel = pmc_pass(workload, seed, kernel_part, [counter])
+        if got is None:
+            return None, kernel
+        kb.update(got)
     return int((2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0), (
         "live: rocprofv3 --pmc FETCH_SIZE (%.1f KB) and --pmc WRITE_SIZE (%.1f KB), separate passes of one launch of this build on this box "
         "(`bench.py --workload %s --steps 1 --warmup 0 --seed %d`, %s; %.0f s for both); %s" % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], workload, seed, kernel,
                                                                                       time.time() - t0, TRAFFIC_FORMULA))
+
+
+def live_issue(workload, seed, kernel_part, samples, compute_units, spp=32):
+    """What the HBM roofline does not show: how busy the vector ALUs are and how full their instructions. One more PMC pass, of a `spp`-spp
+    launch of the same kernel (SQ counters count the same per sample at any length): SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES and
+    SQ_THREAD_CYCLES_VALU are quad-cycles (MI355X_MICROARCH.md, the PMC units table). The stage-scheduled kernel is persistent -- every
+    wave lives as long as the launch -- so a wave's cycles ARE the kernel's:  VALU busy = (SQ_ACTIVE_INST_VALU / SIMDs) / (SQ_WAVE_CYCLES
+    / SQ_WAVES);  lane occupancy = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)."""
+    counters = ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU"]
+    got, kernel = pmc_pass(workload, seed, kernel_part, counters, ["--spp", str(spp)])
+    if got is None:
+        return {"source": "no pass in this run: %s" % kernel}
+    simds = 4 * compute_units
+    persistent = got["SQ_WAVES"] <= 8 * simds  # at most the resident set: nothing was launched behind it
+    return {
+        "valu_busy": round((got["SQ_ACTIVE_INST_VALU"] / simds) / (got["SQ_WAVE_CYCLES"] / got["SQ_WAVES"]), 4) if persistent else None,
+        "lane_occupancy": round(got["SQ_THREAD_CYCLES_VALU"] / (64.0 * got["SQ_ACTIVE_INST_VALU"]), 4),
+        "valu_instructions_per_sample": round(got["SQ_INSTS_VALU"] / (samples * spp), 1),
+        "waves": int(got["SQ_WAVES"]), "simds": simds,
+        "source": "live: rocprofv3 --pmc %s on one %d-spp launch of %s in this run; valu_busy = share of the quad-cycles a SIMD's waves are resident in "
+                  "which its vector ALU executes an instruction; lane_occupancy = active lanes per vector instruction / 64" % (" ".join(counters), spp, kernel),
+        "reading": "a kernel whose vector ALUs are busy most of the time at a lane occupancy well under 1 is bound by vector issue, not by HBM: "
+                   "`roofline.frac` (algorithmic bytes over the HBM peak) is the contract's figure, this is the binding one",
+    }
 
 
 class Workload:
@@ -641,6 +674,9 @@ def main():
             staged = wl.kernel_name().startswith("render_kernel_sm")
             live = live_traffic(wl.name, args.seed, "render_kernel_sm<false" if staged else "render_kernel<false")
         line["roofline"] = wl.roofline(counters, kernel_ms, launches // max(args.steps, 1), live)
+        if live is not None and live[0] is not None:
+            line["issue"] = live_issue(wl.name, args.seed, "render_kernel_sm<false" if staged else "render_kernel<false", wl.width * wl.height,
+                                       torch.cuda.get_device_properties(local_rank).multi_processor_count)
         if world_size == 1 and not args.no_traversal:
             line["traversal_roofline"] = traversal_roofline(local_rank)
         if world_size == 1 and args.workload == "C3" and not args.no_c2 and not wl.reduced:
