@@ -252,7 +252,7 @@ TRAFFIC_FORMULA = ("(2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled p
                    "64 B); WRITE_SIZE is exact for float atomics; Infinity-Cache hits are counted (the counters sit at the L2's fabric side)")
 
 
-def pmc_pass(workload, seed, kernel_part, counters, extra_args=(), pass_seconds=150):
+def pmc_pass(workload, seed, kernel_part, counters, extra_args=(), pass_seconds=90):
     """One child run of this file's one launch under `rocprofv3 --pmc <counters>` (no trace domain beside them, the program itself
     behind `--`) -> ({counter: mean over the launches of the kernel whose name contains kernel_part}, the kernel's name), or
     (None, why not). The child is an ordinary child process in a process group of its own: a pass that outlives its limit is ended
