@@ -132,6 +132,18 @@ if rays:
                 print("   " + line)
             verdict = "tie" if tie else ("order-dependent in the reference: a sphere hit nearer than its own box's entry" if garbage else "DEFECT: the closest hit differs")
             break
+if verdict.startswith("no ray"):
+    # The closest hits agree; the render's shadow test is an any-hit walk, though: a sphere hit without digits that lies inside the
+    # blocking limit while the sphere's own box begins beyond the oracle's closest hit blocks here (the box is within the cut-off's margin) and
+    # is skipped by the reference when it has met that closest hit first -- its tree's order again.
+    for m in shadow:
+        ray = np.array([float(v) for v in m[:6]], dtype=np.float32)
+        limit, oracle_blocked = np.float32(float(m[8])), m[9] == "1"
+        for line in inconsistent_spheres(ray):
+            near = np.float32(float(re.search(r"routine says ([-+0-9.einfa]+)", line).group(1)))
+            if near > np.float32(1e-4) and np.float32(near * near) < limit and not oracle_blocked:
+                print("shadow ray", ray, "limit", limit, "oracle: hit at", m[7], "(not a blocker)\n   " + line + " -- inside the limit: an any-hit walk that enters the box counts it")
+                verdict = "order-dependent in the reference: a sphere hit nearer than its own box's entry decides a shadow ray"
 print("verdict:", verdict)
 if verdict.startswith("no ray"):
     print(text)
