@@ -158,7 +158,7 @@ bool instr_reads_wavelength(const PyrInstr& ins) {
     }
 }
 
-DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
+DevProgram pack_program(const PyrInstr* instrs, const PyrProgram& p) {
     DevProgram o{};
     o.kind = p.kind;
     o.constant = p.constant;
@@ -169,7 +169,7 @@ DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
     o.fast = FAST_NONE;
     o.tape_form = TAPE_FORM_DIRECT;
     if (p.kind != PYR_PROGRAM_INSTRUCTIONS) return o;
-    const PyrInstr* I = d->instrs + p.first_instr;
+    const PyrInstr* I = instrs + p.first_instr;
     for (uint32_t k = 0; k < p.num_instrs; ++k)
         if (instr_reads_wavelength(I[k])) o.reads_wavelength = 1;
     // the tape form of a program the interpreter has to run (device_scene.h TapeForm); a fast shape found below is DIRECT again
@@ -218,6 +218,112 @@ DevProgram pack_program(const PyrSceneDesc* d, const PyrProgram& p) {
     }
     if (o.fast != FAST_NONE) o.tape_form = TAPE_FORM_DIRECT;
     return o;
+}
+
+bool instr_depends_on_wavelength(const PyrInstr& ins) { return (ins.deps & PYR_DEP_WAVELENGTH) != 0u || instr_reads_wavelength(ins); }
+
+// TAPE_FORM_PRODUCT (device_scene.h): a number program without a tape form of its own whose value is a chain of products
+// ((lambda * h1) * h2) ... -- ONE factor made by number-only instructions that depend on the wavelength and on nothing else, every other
+// factor made by instructions that do not depend on the wavelength -- is split into those two instruction lists, appended to `instrs`
+// as two programs (the hit side first; registers keep their numbers). `chain` receives the hit side's registers in the order the
+// products are formed, innermost first (at most three). Returns false when the program does not factor that way.
+bool split_product(std::vector<PyrInstr>& instrs, const PyrProgram& p, PyrProgram& hit, PyrProgram& lambda, std::vector<uint32_t>& chain) {
+    if (p.kind != PYR_PROGRAM_INSTRUCTIONS || p.output_kind != PYR_OUTPUT_NUMBER || p.num_instrs < 3) return false;
+    const size_t first = p.first_instr, end = first + p.num_instrs;
+    auto writes_number = [](const PyrInstr& ins) {
+        return ins.op == PYR_OP_NUMBER || ins.op == PYR_OP_SPECTRUM || ins.op == PYR_OP_BLACKBODY || ins.op == PYR_OP_CLAMP || ins.op == PYR_OP_FRESNEL ||
+               ins.op == PYR_OP_MONO_TEXTURE || ins.op == PYR_OP_RGB_SPECTRUM || ((ins.op == PYR_OP_BINARY || ins.op == PYR_OP_MIX) && ins.value_type == PYR_VT_NUMBER);
+    };
+    auto is_number_mul = [](const PyrInstr& ins) { return ins.op == PYR_OP_BINARY && ins.value_type == PYR_VT_NUMBER && ins.operator_ == PYR_BIN_MUL; };
+    auto hit_deps = [](const PyrInstr& ins) { return (ins.deps & (PYR_DEP_NORMAL | PYR_DEP_INCIDENT | PYR_DEP_TEXTURE)) != 0u; };
+    auto writer_before = [&](uint32_t reg, size_t before) { // the instruction whose result a read of number register `reg` at `before` sees
+        for (size_t k = before; k-- > first;)
+            if (writes_number(instrs[k]) && instrs[k].output == reg) return (long)k;
+        return -1L;
+    };
+    auto written_once_more = [&](uint32_t reg, size_t after) { // ... and nobody writes it again (the split programs read registers at their ends)
+        for (size_t k = after + 1; k < end; ++k)
+            if (writes_number(instrs[k]) && instrs[k].output == reg) return true;
+        return false;
+    };
+    // from the closing product down to the factor that depends on the wavelength alone
+    std::vector<bool> on_chain(p.num_instrs, false);
+    size_t cur = end - 1;
+    if (!is_number_mul(instrs[cur]) || instrs[cur].output != p.output_reg) return false;
+    std::vector<uint32_t> outer_first;
+    long lambda_writer = -1;
+    for (;;) {
+        const PyrInstr mul = instrs[cur];
+        if (mul.a == mul.b) return false;
+        const long wa = writer_before(mul.a, cur), wb = writer_before(mul.b, cur);
+        if (wa < 0 || wb < 0) return false;
+        const bool la = instr_depends_on_wavelength(instrs[(size_t)wa]), lb = instr_depends_on_wavelength(instrs[(size_t)wb]);
+        if (la == lb) return false;
+        const long lw = la ? wa : wb, hw = la ? wb : wa;
+        const uint32_t hit_reg = la ? mul.b : mul.a;
+        if (written_once_more(hit_reg, (size_t)hw) || outer_first.size() == 3) return false;
+        outer_first.push_back(hit_reg);
+        on_chain[cur - first] = true;
+        if (hit_deps(instrs[(size_t)lw])) { // the wavelength side is itself a product with something of the hit in it: one level down
+            if (!is_number_mul(instrs[(size_t)lw])) return false;
+            cur = (size_t)lw;
+            continue;
+        }
+        lambda_writer = lw;
+        break;
+    }
+    if (written_once_more(instrs[(size_t)lambda_writer].output, (size_t)lambda_writer)) return false;
+    std::vector<PyrInstr> hit_list, lambda_list;
+    for (size_t k = first; k < end; ++k) {
+        const PyrInstr& ins = instrs[k];
+        if (on_chain[k - first]) continue;
+        if (instr_depends_on_wavelength(ins)) {
+            const bool number_op = ins.op == PYR_OP_SPECTRUM || ins.op == PYR_OP_BLACKBODY || ins.op == PYR_OP_CLAMP || ((ins.op == PYR_OP_BINARY || ins.op == PYR_OP_MIX) && ins.value_type == PYR_VT_NUMBER);
+            if (!number_op || hit_deps(ins) || k > (size_t)lambda_writer) return false; // a second factor that reads the wavelength, or one that reads the hit too
+            lambda_list.push_back(ins);
+        } else {
+            hit_list.push_back(ins);
+            if (ins.op == PYR_OP_NUMBER && k < (size_t)lambda_writer) lambda_list.push_back(ins); // a constant either side may read
+        }
+    }
+    if (hit_list.empty() || lambda_list.empty()) return false;
+    // the wavelength side must be closed: every number register it reads was written by one of its own instructions (a constant that
+    // is not a NumberValue -- 2 * 3 left unfolded -- stands on the hit side only, and the program keeps the online form)
+    {
+        bool written[PYR_MAX_NUMBER_REGISTERS] = {};
+        bool closed = true;
+        auto reads = [&](const PyrOperand& o) {
+            if (o.kind == PYR_OPERAND_REGISTER && !(o.bits < PYR_MAX_NUMBER_REGISTERS && written[o.bits])) closed = false;
+        };
+        auto reads_register = [&](uint32_t r) {
+            if (!(r < PYR_MAX_NUMBER_REGISTERS && written[r])) closed = false;
+        };
+        for (const PyrInstr& ins : lambda_list) {
+            switch (ins.op) {
+            case PYR_OP_SPECTRUM: reads(ins.x); break;
+            case PYR_OP_BLACKBODY: reads(ins.x), reads(ins.y); break;
+            case PYR_OP_CLAMP: reads(ins.x), reads(ins.y), reads(ins.z); break;
+            case PYR_OP_BINARY: reads_register(ins.a), reads_register(ins.b); break;
+            case PYR_OP_MIX: reads(ins.x), reads_register(ins.a), reads_register(ins.b); break;
+            default: break; // NumberValue
+            }
+            if (ins.output < PYR_MAX_NUMBER_REGISTERS) written[ins.output] = true;
+        }
+        if (!closed) return false;
+    }
+    chain.assign(outer_first.rbegin(), outer_first.rend());
+    for (uint32_t reg : chain)
+        if (reg >= PYR_MAX_NUMBER_REGISTERS) return false;
+    hit = lambda = p;
+    hit.first_instr = (uint32_t)instrs.size();
+    hit.num_instrs = (uint32_t)hit_list.size();
+    hit.output_reg = chain[0];
+    instrs.insert(instrs.end(), hit_list.begin(), hit_list.end());
+    lambda.first_instr = (uint32_t)instrs.size();
+    lambda.num_instrs = (uint32_t)lambda_list.size();
+    lambda.output_reg = instrs[(size_t)lambda_writer].output;
+    instrs.insert(instrs.end(), lambda_list.begin(), lambda_list.end());
+    return true;
 }
 
 } // namespace
@@ -411,7 +517,29 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         }
     }
     std::vector<DevProgram> programs(d->num_programs);
-    for (uint32_t i = 0; i < d->num_programs; ++i) programs[i] = pack_program(d, d->programs[i]);
+    for (uint32_t i = 0; i < d->num_programs; ++i) programs[i] = pack_program(d->instrs, d->programs[i]);
+    // programs without a tape form that factor into a hit side and a wavelength side get both as programs of their own, behind the
+    // caller's (TAPE_FORM_PRODUCT); the instruction array grows by their instructions
+    std::vector<PyrInstr> instrs(d->instrs, d->instrs + d->num_instrs);
+    for (uint32_t i = 0; i < d->num_programs; ++i) {
+        if (programs[i].kind != PYR_PROGRAM_INSTRUCTIONS || programs[i].tape_form != TAPE_FORM_NONE) continue;
+        const size_t instrs_before = instrs.size();
+        PyrProgram hit, lambda;
+        std::vector<uint32_t> chain;
+        if (!split_product(instrs, d->programs[i], hit, lambda, chain)) continue;
+        const DevProgram dev_hit = pack_program(instrs.data(), hit), dev_lambda = pack_program(instrs.data(), lambda);
+        if (dev_hit.tape_form != TAPE_FORM_HIT_VALUE || !(dev_lambda.tape_form == TAPE_FORM_LAMBDA || dev_lambda.fast != FAST_NONE)) {
+            instrs.resize(instrs_before);
+            continue;
+        }
+        programs[i].tape_form = TAPE_FORM_PRODUCT;
+        programs[i].tape_hit_program = (uint32_t)programs.size();
+        programs[i].tape_lambda_program = (uint32_t)programs.size() + 1u;
+        programs[i].tape_chain = (uint32_t)chain.size();
+        for (size_t c = 0; c < chain.size(); ++c) programs[i].tape_chain |= chain[c] << (4u + 4u * (uint32_t)c); // PYR_MAX_NUMBER_REGISTERS == 16
+        programs.push_back(dev_hit);
+        programs.push_back(dev_lambda);
+    }
 
     bool needs_interpreter = false, uses_textures = false;
     for (const DevProgram& pr : programs)
@@ -523,7 +651,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     if ((rc = s->materials.upload(d->materials, (size_t)d->num_materials * sizeof(PyrMaterial)))) return rc;
     if ((rc = s->components.upload(d->components, (size_t)d->num_components * sizeof(PyrComponent)))) return rc;
     if ((rc = s->programs.upload(programs.data(), programs.size() * sizeof(DevProgram)))) return rc;
-    if ((rc = s->instrs.upload(d->instrs, (size_t)d->num_instrs * sizeof(PyrInstr)))) return rc;
+    if ((rc = s->instrs.upload(instrs.data(), instrs.size() * sizeof(PyrInstr)))) return rc;
     if ((rc = s->spectra.upload(d->spectra, (size_t)d->num_spectra * sizeof(PyrSpectrum)))) return rc;
     if ((rc = s->spectrum_data.upload(d->spectrum_data, (size_t)d->num_spectrum_floats * 4))) return rc;
     if ((rc = s->rgb_basis.upload(d->rgb_basis, d->rgb_basis ? (size_t)d->rgb_basis_count * 12 : 0))) return rc;
@@ -559,7 +687,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     v.num_nodes = (uint32_t)bvh.nodes.size();
     v.num_prims = (uint32_t)prims.size();
     v.num_spectra = d->num_spectra;
-    v.num_programs = d->num_programs;
+    v.num_programs = (uint32_t)programs.size();
     v.num_spectrum_floats = d->num_spectrum_floats;
     v.num_materials = d->num_materials;
     v.num_components = d->num_components;
@@ -568,7 +696,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         // lamp records. <= 16 KB, and only for scenes too big to live in LDS themselves: a small scene leaves L1 to the tables
         // (C2: staging the spectra costs a workgroup per CU and is 0.9x), a big one evicts them all the time (C3: 1.33x)
         const uint64_t floats = (uint64_t)d->num_spectra * (sizeof(PyrSpectrum) / 4) + d->num_spectrum_floats + (uint64_t)d->num_materials * (sizeof(PyrMaterial) / 4) +
-                                (uint64_t)d->num_components * (sizeof(PyrComponent) / 4) + (uint64_t)d->num_programs * (sizeof(DevProgram) / 4) +
+                                (uint64_t)d->num_components * (sizeof(PyrComponent) / 4) + (uint64_t)programs.size() * (sizeof(DevProgram) / 4) +
                                 (uint64_t)d->num_lamps * (sizeof(DevLamp) / 4);
         const bool big_scene = (size_t)bvh.nodes.size() * 64 + prims.size() * 48 > 8 * 1024;
         v.lds_table_floats = (floats <= 4096 && big_scene) ? (uint32_t)floats : 0;
@@ -579,9 +707,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     // component, of a lamp, the sky -- must have a tape form; the value slots the replay keeps in LDS (kTapeEagerSlots = 8: one
     // holds 1.0, three the RGB basis when a HIT_RGB program exists) must hold every spectrum-reading fast program (counted here
     // without the sharing the kernel finds, so never fewer), and the prepared programs must fit their LDS table (128).
-    v.hit_tape = v.rgb_records = 0;
+    v.hit_tape = v.rgb_records = v.micro_records = 0;
     if (needs_interpreter) {
-        bool ok = d->num_programs <= 128;
+        bool ok = programs.size() <= 128;
         // value slots of the replay: one per LAMBDA program and one per DISTINCT fast shape -- programs of the same shape, factor and
         // spectrum share a slot (kernels.hip prepare_tape_tables `alike`: C3's three white walls are three programs over one spectrum)
         uint32_t fast_programs = 0;
@@ -605,6 +733,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             if (pr.kind != PYR_PROGRAM_INSTRUCTIONS) return;
             if (pr.tape_form == TAPE_FORM_NONE) ok = false;
             if (pr.tape_form == TAPE_FORM_HIT_RGB) v.rgb_records = 1u;
+            if (pr.tape_form == TAPE_FORM_HIT_RGB || pr.tape_form == TAPE_FORM_PRODUCT) v.micro_records = 1u;
         };
         for (uint32_t i = 0; i < d->num_components; ++i) colour(d->components[i].color_program);
         for (const DevLamp& l : lamps) colour(l.color_program);
@@ -613,7 +742,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         const char* off = std::getenv("PYRITE_HIT_TAPE"); // A/B and tests: PYRITE_HIT_TAPE=0 keeps the online form (read at scene creation)
         if (off && off[0] == '0') ok = false;
         v.hit_tape = ok ? 1u : 0u;
-        if (!ok) v.rgb_records = 0u;
+        if (!ok) v.rgb_records = v.micro_records = 0u;
     }
     v.shadow_margin = d->num_spheres != 0 ? 1.01f : 1.001f; // device_scene.h
     v.hero_only_records = 0;

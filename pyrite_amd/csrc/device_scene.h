@@ -72,9 +72,15 @@ enum FastProgram : uint32_t {
 //   LAMBDA     a function of the wavelength alone made of numbers only (`blackbody(4000) * 3`, a product or mix of spectra): like a
 //              fast shape it gets a value slot -- the replay evaluates it once per item with a small number-only interpreter
 //              (kernels.hip lambda_eval) -- and the record names it;
-//   NONE       needs an interpreter run per hit AND wavelength (a mix of spectra by a fresnel term, a texture times a spectrum): a
+//   PRODUCT    the program's value is a chain of products ((l * h1) * h2) ... with ONE factor l that depends on the wavelength alone in
+//              LAMBDA's sense and up to three factors that depend on the hit alone (a mono texture times a spectrum times a number: the
+//              textured lamps of the fuzz scenes and of the generated textures scene, a tinted mask): api.cpp splits it into two programs
+//              of its own instructions -- the hit side (HIT_VALUE) and the wavelength side (DIRECT or LAMBDA, with a value slot) -- the
+//              interpreter runs the hit side once per hit, and records carry h1 to the slot's value, h2 ... to that product and the
+//              contribution's factor to the result: the products the interpreter and `contribute` form, in their order;
+//   NONE       needs an interpreter run per hit AND wavelength (a mix of spectra by a fresnel term): a
 //              scene with such a COLOUR program keeps the online form of round 3 (Walker::contribute_pending).
-enum TapeForm : uint32_t { TAPE_FORM_DIRECT = 0, TAPE_FORM_HIT_VALUE = 1, TAPE_FORM_HIT_RGB = 2, TAPE_FORM_NONE = 3, TAPE_FORM_LAMBDA = 4 };
+enum TapeForm : uint32_t { TAPE_FORM_DIRECT = 0, TAPE_FORM_HIT_VALUE = 1, TAPE_FORM_HIT_RGB = 2, TAPE_FORM_NONE = 3, TAPE_FORM_LAMBDA = 4, TAPE_FORM_PRODUCT = 5 };
 
 struct DevProgram {
     uint32_t kind; // PyrProgramKind
@@ -87,6 +93,8 @@ struct DevProgram {
     uint32_t reads_wavelength; // some executed operand is Input(Wavelength): ProbabilityInput::wavelength_used
     uint32_t tape_form;        // TapeForm
     uint32_t tape_rgb_reg;     // HIT_RGB: the rgb register the closing RgbSpectrumValue reads
+    uint32_t tape_hit_program, tape_lambda_program; // PRODUCT: the two programs api.cpp made of this one's instructions
+    uint32_t tape_chain; // PRODUCT: bits 0-3 the number of hit-side factors (1-3), bits 4-7, 8-11, 12-15 their number registers, innermost product first
 };
 
 struct DevScene {
@@ -134,6 +142,7 @@ struct DevScene {
     // for this scene too and the interpreter runs once per hit instead of once per hit and wavelength
     uint32_t hit_tape;
     uint32_t rgb_records; // some colour program is HIT_RGB: its contributions are four records (three coefficients + the factor)
+    uint32_t micro_records; // some colour program is HIT_RGB or PRODUCT: the replay reads bits 12-13 of a record (kernels.hip TAPE_RGB_*)
     // Boxes a shadow ray may skip lie beyond limit * shadow_margin (+ 1e-3), limit = the blocking limit (a squared distance): 1.001
     // covers the ulps between a box's entry distance and a triangle's hit distance; scenes with spheres take 1.01 -- collision's
     // sphere routine loses every digit of l.l - tca^2 for a ray that passes at a thousand radii or more and then reports hits up to a

@@ -2252,7 +2252,10 @@ constexpr uint32_t kTapeOneSlot = kTapeEagerSlots - 1; // the value row that hol
 // Eager records of a HIT_RGB contribution (device_scene.h TapeForm; scenes with S.rgb_records): bits 12-13 of the word say what the
 // record does with m = value[slot] * s -- 1: t = m (first coefficient times the red basis), 2: t = t + m (green, blue),
 // 3: m = t * s, then applied like any record (the contribution's factor). 0: an ordinary record.
-constexpr uint32_t TAPE_RGB_SHIFT = 12, TAPE_RGB_FIRST = 1u << TAPE_RGB_SHIFT, TAPE_RGB_NEXT = 2u << TAPE_RGB_SHIFT, TAPE_RGB_APPLY = 3u << TAPE_RGB_SHIFT;
+// A PRODUCT contribution uses the same accumulator: 1 with the wavelength side's slot and the first hit factor, 4: t = t * m (m = 1.0 * the next
+// hit factor) for each further one, then 3.
+constexpr uint32_t TAPE_RGB_SHIFT = 12, TAPE_RGB_FIRST = 1u << TAPE_RGB_SHIFT, TAPE_RGB_NEXT = 2u << TAPE_RGB_SHIFT, TAPE_RGB_APPLY = 3u << TAPE_RGB_SHIFT,
+                   TAPE_RGB_TIMES = 4u << TAPE_RGB_SHIFT;
 static_assert(BLOCK == 1u << TAPE_EAGER_SLOT_SHIFT, "an eager record's slot field is an index into rows of BLOCK floats");
 
 // Where record `op` of tape column `column` lives: [op][column], a row of one record index is contiguous (512 B per wave).
@@ -2420,12 +2423,13 @@ struct Walker {
                 Vm vm;
                 float cp = c_cp, hit_value = 1.0f;
                 const DevProgram colour = S.programs[c_color];
-                const bool run_colour = colour.tape_form == TAPE_FORM_HIT_VALUE || colour.tape_form == TAPE_FORM_HIT_RGB; // the interpreter runs its hit part; everything else is looked up by the replay
+                const bool product = colour.tape_form == TAPE_FORM_PRODUCT; // its hit side is a program of its own (api.cpp split_product)
+                const bool run_colour = colour.tape_form == TAPE_FORM_HIT_VALUE || colour.tape_form == TAPE_FORM_HIT_RGB || product; // the interpreter runs its hit part; everything else is looked up by the replay
                 // job 0: the probability program in full (it is evaluated for the hero wavelength only); job 1: the colour program's
                 // instructions that do not depend on the wavelength -- all of a HIT_VALUE program, all but the closing one of a HIT_RGB
                 for (uint32_t job = c_probability >= 0 ? 0u : 1u; job < 2u; ++job) {
                     if (job == 1u && !run_colour) break;
-                    const uint32_t id = job == 0u ? (uint32_t)c_probability : c_color;
+                    const uint32_t id = job == 0u ? (uint32_t)c_probability : (product ? colour.tape_hit_program : c_color);
                     const DevProgram prog = S.programs[id];
                     const bool interpreted = prog.kind != PYR_PROGRAM_CONSTANT && prog.fast == FAST_NONE;
                     float v;
@@ -2448,6 +2452,13 @@ struct Walker {
                     tape_push(L, c_kind == CONTRIB_ADD ? TAPE_ADD : TAPE_MUL, c_color, factor, !c_companions);
                 } else if (colour.tape_form == TAPE_FORM_HIT_VALUE) {
                     tape_push_raw(L, flags | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), hit_value * factor); // value * factor is the product contribute forms
+                } else if (product) { // t = value[slot of the wavelength side] * h1, t = t * h2 ...: the program's products in its order; then t * factor
+                    const uint32_t slot = tape_prepared != nullptr ? tape_prepared[8 * colour.tape_lambda_program + 7] : kTapeOneSlot; // (a hit-tape scene always replays eagerly: api.cpp)
+                    const uint32_t hero = c_companions ? 0u : TAPE_HERO_ONLY, factors = colour.tape_chain & 15u;
+                    tape_push_raw(L, hero | TAPE_RGB_FIRST | (slot << TAPE_EAGER_SLOT_SHIFT), vm.num[(colour.tape_chain >> 4) & 15u]);
+                    for (uint32_t k = 1; k < factors; ++k)
+                        tape_push_raw(L, hero | TAPE_RGB_TIMES | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), vm.num[(colour.tape_chain >> (4u + 4u * k)) & 15u]);
+                    tape_push_raw(L, flags | TAPE_RGB_APPLY | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), factor);
                 } else { // HIT_RGB: c0 * basis_r + c1 * basis_g + c2 * basis_b (execution_context.rs:140-152), then times the factor
                     const float* c = vm.rgb[colour.tape_rgb_reg & (PYR_MAX_VECTOR_REGISTERS - 1)];
                     const uint32_t hero = c_companions ? 0u : TAPE_HERO_ONLY;
@@ -2934,13 +2945,13 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 float values[ROWS];
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) values[j] = spectral_values[words[j] & TAPE_EAGER_SLOT_MASK]; // slot << 8 is slot * BLOCK
-                if (RGB && S.rgb_records != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it
+                if (RGB && S.micro_records != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it; PRODUCT: one and one
                     const uint32_t not_mine = hero ? 0u : TAPE_HERO_ONLY;
 #pragma unroll
                     for (uint32_t j = 0; j < ROWS; ++j) {
                         const float m = values[j] * factors[j];
-                        const uint32_t op = (words[j] >> TAPE_RGB_SHIFT) & 3u;
-                        rgb_sum = op == 1u ? m : (op == 2u ? rgb_sum + m : rgb_sum);
+                        const uint32_t op = (words[j] >> TAPE_RGB_SHIFT) & 7u;
+                        rgb_sum = op == 1u ? m : (op == 2u ? rgb_sum + m : (op == 4u ? rgb_sum * m : rgb_sum));
                         const float mm = op == 3u ? rgb_sum * factors[j] : m;
                         const bool apply = ((words[j] & not_mine) == 0u) & ((op == 0u) | (op == 3u));
                         const bool adds = (int)words[j] < 0;
@@ -3524,7 +3535,7 @@ static uint32_t short_stack_levels(const DevScene& scene, size_t other_bytes, ui
 // (tracer.rs:257), one closing ADD (emission or sky).
 // A contribution whose colour program is HIT_RGB is four records (three coefficients and the factor).
 uint32_t tape_ops_bound(const DevScene& scene, const RenderLaunch& launch) {
-    return (launch.bounces + 2u * launch.light_samples + 1u) * (scene.rgb_records ? 4u : 1u) + launch.bounces;
+    return (launch.bounces + 2u * launch.light_samples + 1u) * (scene.micro_records ? 4u : 1u) + launch.bounces; // HIT_RGB: four records a contribution; PRODUCT: two to four
 }
 uint32_t tape_lanes_bound(int num_cus) { return (uint32_t)num_cus * 8u * BLOCK; } // launch_render never starts more than 8 blocks per CU
 constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for the replay (4 KB); scenes with more use the HBM records

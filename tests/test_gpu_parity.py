@@ -135,7 +135,7 @@ def test_all_schedulers_give_the_oracle_film(name, scheduler, gpu_lib, monkeypat
 HIT_TAPE_CASES = {  # name: (project, does the scene record a tape when it may?)
     "textures_reference_example": (lambda: scenes.textures_reference_example(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "textures"), 96, 48, 8), True),
     "spheres_example": (CASES["spheres_example"], True),
-    "textures_example": (CASES["textures_example"], False),  # a mono texture times a spectrum: an interpreter run per wavelength
+    "textures_example": (CASES["textures_example"], True),   # a mono texture times a spectrum: a PRODUCT form -- the texture once per hit, the spectrum in the replay
     "lamps_example": (CASES["lamps_example"], True),         # a blackbody lamp (a LAMBDA form: evaluated once per replay item), an rgb() lamp
 }
 
@@ -144,7 +144,7 @@ HIT_TAPE_CASES = {  # name: (project, does the scene record a tape when it may?)
 @pytest.mark.parametrize("name", sorted(HIT_TAPE_CASES))
 def test_interpreter_scenes_with_and_without_the_hit_tape(name, hit_tape, gpu_lib, monkeypatch):
     """Round 4: a scene with interpreter programs whose colour programs all have a tape form (device_scene.h TapeForm: textures,
-    spheres, lamps; not the generated textures scene, where a mono texture multiplies a spectrum) records a spectral tape -- the interpreter runs once per
+    spheres, lamps, and the generated textures scene, whose mono texture times a spectrum is a PRODUCT form) records a spectral tape -- the interpreter runs once per
     hit, the replay does the per-wavelength part. PYRITE_HIT_TAPE=0 (read at scene creation) keeps round 3's online form. Both
     are the oracle's film; and with the tape shrunk under its bound the hit-tape form -- and only it -- reports the overflow."""
     from pyrite_amd._lib import PyriteGpuError

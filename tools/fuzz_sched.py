@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool (GPU box): python tools/fuzz_sched.py scene|soup SEED [REPEATS] -- one fuzz case on every scheduler, several
+"""Developer tool (GPU box): python tools/fuzz_sched.py scene|soup|mesh SEED [REPEATS] -- one fuzz case on every scheduler, several
 times: which scheduler differs from the oracle, where, and is it the same every time?"""
 import os, sys
 import numpy as np
@@ -14,8 +14,8 @@ from pyrite_amd.renderer import Camera, Renderer, World
 from test_gpu_fuzz import random_project, random_soup
 from test_gpu_parity import rel_l2
 
-if kind == "scene":
-    project = random_project(1000 + seed)
+if kind in ("scene", "mesh"):
+    project = random_project(500000 + seed, knot=True) if kind == "mesh" else random_project(1000 + seed)
     world, cam, r, _ = scenes.build(project, seed=seed)
     W, H = project["image"]["width"], project["image"]["height"]
 else:
