@@ -522,7 +522,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     // caller's (TAPE_FORM_PRODUCT); the instruction array grows by their instructions
     std::vector<PyrInstr> instrs(d->instrs, d->instrs + d->num_instrs);
     for (uint32_t i = 0; i < d->num_programs; ++i) {
-        if (programs[i].kind != PYR_PROGRAM_INSTRUCTIONS || programs[i].tape_form != TAPE_FORM_NONE) continue;
+        if (programs[i].kind != PYR_PROGRAM_INSTRUCTIONS || programs[i].tape_form != TAPE_FORM_NONE || programs.size() + 2 > 128) continue; // (a hit tape takes at most 128 programs)
         const size_t instrs_before = instrs.size();
         PyrProgram hit, lambda;
         std::vector<uint32_t> chain;
@@ -533,10 +533,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             continue;
         }
         programs[i].tape_form = TAPE_FORM_PRODUCT;
-        programs[i].tape_hit_program = (uint32_t)programs.size();
-        programs[i].tape_lambda_program = (uint32_t)programs.size() + 1u;
-        programs[i].tape_chain = (uint32_t)chain.size();
-        for (size_t c = 0; c < chain.size(); ++c) programs[i].tape_chain |= chain[c] << (4u + 4u * (uint32_t)c); // PYR_MAX_NUMBER_REGISTERS == 16
+        uint32_t packed = (uint32_t)programs.size() | (((uint32_t)programs.size() + 1u) << 8) | ((uint32_t)chain.size() << 16); // device_scene.h DevProgram::tape_rgb_reg
+        for (size_t c = 0; c < chain.size(); ++c) packed |= chain[c] << (20u + 4u * (uint32_t)c); // PYR_MAX_NUMBER_REGISTERS == 16
+        programs[i].tape_rgb_reg = packed;
         programs.push_back(dev_hit);
         programs.push_back(dev_lambda);
     }
@@ -707,7 +706,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     // component, of a lamp, the sky -- must have a tape form; the value slots the replay keeps in LDS (kTapeEagerSlots = 8: one
     // holds 1.0, three the RGB basis when a HIT_RGB program exists) must hold every spectrum-reading fast program (counted here
     // without the sharing the kernel finds, so never fewer), and the prepared programs must fit their LDS table (128).
-    v.hit_tape = v.rgb_records = v.micro_records = 0;
+    v.hit_tape = v.rgb_records = v.micro_records = v.product_records = 0;
     if (needs_interpreter) {
         bool ok = programs.size() <= 128;
         // value slots of the replay: one per LAMBDA program and one per DISTINCT fast shape -- programs of the same shape, factor and
@@ -734,6 +733,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
             if (pr.tape_form == TAPE_FORM_NONE) ok = false;
             if (pr.tape_form == TAPE_FORM_HIT_RGB) v.rgb_records = 1u;
             if (pr.tape_form == TAPE_FORM_HIT_RGB || pr.tape_form == TAPE_FORM_PRODUCT) v.micro_records = 1u;
+            if (pr.tape_form == TAPE_FORM_PRODUCT) v.product_records = 1u;
         };
         for (uint32_t i = 0; i < d->num_components; ++i) colour(d->components[i].color_program);
         for (const DevLamp& l : lamps) colour(l.color_program);
@@ -742,7 +742,7 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         const char* off = std::getenv("PYRITE_HIT_TAPE"); // A/B and tests: PYRITE_HIT_TAPE=0 keeps the online form (read at scene creation)
         if (off && off[0] == '0') ok = false;
         v.hit_tape = ok ? 1u : 0u;
-        if (!ok) v.rgb_records = v.micro_records = 0u;
+        if (!ok) v.rgb_records = v.micro_records = v.product_records = 0u;
     }
     v.shadow_margin = d->num_spheres != 0 ? 1.01f : 1.001f; // device_scene.h
     v.hero_only_records = 0;

@@ -92,9 +92,10 @@ struct DevProgram {
     float fast_scale;         // c of the fast forms
     uint32_t reads_wavelength; // some executed operand is Input(Wavelength): ProbabilityInput::wavelength_used
     uint32_t tape_form;        // TapeForm
-    uint32_t tape_rgb_reg;     // HIT_RGB: the rgb register the closing RgbSpectrumValue reads
-    uint32_t tape_hit_program, tape_lambda_program; // PRODUCT: the two programs api.cpp made of this one's instructions
-    uint32_t tape_chain; // PRODUCT: bits 0-3 the number of hit-side factors (1-3), bits 4-7, 8-11, 12-15 their number registers, innermost product first
+    // HIT_RGB: the rgb register the closing RgbSpectrumValue reads. PRODUCT (one word, so that the record stays twelve: three more were 8 % of
+    // the example scenes' throughput): bits 0-7 / 8-15 the two programs api.cpp made of this one's instructions, the hit side and the
+    // wavelength side; bits 16-19 the number of hit-side factors (1-3), bits 20-23, 24-27, 28-31 their number registers, innermost product first
+    uint32_t tape_rgb_reg;
 };
 
 struct DevScene {
@@ -142,7 +143,8 @@ struct DevScene {
     // for this scene too and the interpreter runs once per hit instead of once per hit and wavelength
     uint32_t hit_tape;
     uint32_t rgb_records; // some colour program is HIT_RGB: its contributions are four records (three coefficients + the factor)
-    uint32_t micro_records; // some colour program is HIT_RGB or PRODUCT: the replay reads bits 12-13 of a record (kernels.hip TAPE_RGB_*)
+    uint32_t product_records; // some colour program is PRODUCT: the scene runs the PRODUCT builds of the hit-tape kernels
+    uint32_t micro_records; // some colour program is HIT_RGB or PRODUCT: the replay reads bits 12-14 of a record (kernels.hip TAPE_RGB_*)
     // Boxes a shadow ray may skip lie beyond limit * shadow_margin (+ 1e-3), limit = the blocking limit (a squared distance): 1.001
     // covers the ulps between a box's entry distance and a triangle's hit distance; scenes with spheres take 1.01 -- collision's
     // sphere routine loses every digit of l.l - tca^2 for a ray that passes at a thousand radii or more and then reports hits up to a

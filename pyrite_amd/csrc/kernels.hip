@@ -28,17 +28,21 @@
 #include "device_scene.h"
 #include "exact_math.h"
 
-// This file is compiled twice and in parallel by pyrite_amd/build.py: -DPYR_TU=0 holds every kernel and launcher but the
-// interpreter builds of render_kernel_sm, -DPYR_TU=1 holds only those (the heaviest kernels to compile: 252-256 VGPRs, the
-// interpreter in line) behind pick_interp_kernel(). Without the macro (-1: tools that compile kernels.hip by themselves, and the
-// -DPYR_PHASE_PROFILE builds, whose device-side counters must live in one translation unit) everything is in one piece.
+// This file is compiled three times and in parallel by pyrite_amd/build.py: -DPYR_TU=0 holds every kernel and launcher but the
+// interpreter builds of render_kernel_sm, -DPYR_TU=1 holds only those (the heaviest kernels to compile: the interpreter in line)
+// behind pick_interp_kernel(), -DPYR_TU=2 their PRODUCT forms behind pick_product_kernel(). Without the macro (-1: tools that compile
+// kernels.hip by themselves, and the -DPYR_PHASE_PROFILE builds, whose device-side counters must live in one translation unit)
+// everything is in one piece.
 #ifndef PYR_TU
 #define PYR_TU -1
 #endif
+#define PYR_TU_MAIN (PYR_TU == 0 || PYR_TU == -1)
+#define PYR_TU_INTERP (PYR_TU == 1 || PYR_TU == -1)
+#define PYR_TU_PRODUCT (PYR_TU == 2 || PYR_TU == -1)
 
 namespace pyr {
 
-#if PYR_TU != 1
+#if PYR_TU_MAIN
 namespace {
 thread_local std::string g_kernel_error;
 }
@@ -2252,8 +2256,8 @@ constexpr uint32_t kTapeOneSlot = kTapeEagerSlots - 1; // the value row that hol
 // Eager records of a HIT_RGB contribution (device_scene.h TapeForm; scenes with S.rgb_records): bits 12-13 of the word say what the
 // record does with m = value[slot] * s -- 1: t = m (first coefficient times the red basis), 2: t = t + m (green, blue),
 // 3: m = t * s, then applied like any record (the contribution's factor). 0: an ordinary record.
-// A PRODUCT contribution uses the same accumulator: 1 with the wavelength side's slot and the first hit factor, 4: t = t * m (m = 1.0 * the next
-// hit factor) for each further one, then 3.
+// A PRODUCT contribution (kernels built with PRODUCT: scenes with such a program) uses the same accumulator: 1 with the wavelength side's
+// slot and the first hit factor, 4: t = t * m (m = 1.0 * the next hit factor) for each further one, then 3.
 constexpr uint32_t TAPE_RGB_SHIFT = 12, TAPE_RGB_FIRST = 1u << TAPE_RGB_SHIFT, TAPE_RGB_NEXT = 2u << TAPE_RGB_SHIFT, TAPE_RGB_APPLY = 3u << TAPE_RGB_SHIFT,
                    TAPE_RGB_TIMES = 4u << TAPE_RGB_SHIFT;
 static_assert(BLOCK == 1u << TAPE_EAGER_SLOT_SHIFT, "an eager record's slot field is an index into rows of BLOCK floats");
@@ -2263,7 +2267,7 @@ static_assert(BLOCK == 1u << TAPE_EAGER_SLOT_SHIFT, "an eager record's slot fiel
 // the 8-byte stores do NOT merge in L2 before they are written back, the neighbouring lanes' records no longer share a sector
 // either, and the fabric saw 85 GB instead of 68 GB per 32-spp frame: C3 -3.5 %, profiles/r04_write_traffic_split.txt.)
 DEV size_t tape_index(uint32_t op, uint32_t lanes, uint32_t column) { return (size_t)op * lanes + column; }
-template <bool COUNT, bool INTERP, bool TAPE = false>
+template <bool COUNT, bool INTERP, bool TAPE = false, bool PRODUCT = false> // PRODUCT: the scene has TAPE_FORM_PRODUCT colour programs (device_scene.h)
 struct Walker {
     uint32_t stage = ST_NEW;
     uint32_t n_ops = 0; // TAPE: records on this path's tape
@@ -2423,13 +2427,16 @@ struct Walker {
                 Vm vm;
                 float cp = c_cp, hit_value = 1.0f;
                 const DevProgram colour = S.programs[c_color];
-                const bool product = colour.tape_form == TAPE_FORM_PRODUCT; // its hit side is a program of its own (api.cpp split_product)
+                // (PRODUCT is a build of its own: the three conditions it adds here, compiled into every interpreter kernel, cost the reference's
+                // example scenes 5-11 % -- these kernels sit on the edge of their register budget)
+                const bool product = PRODUCT && colour.tape_form == TAPE_FORM_PRODUCT; // its hit side is a program of its own (api.cpp split_product)
                 const bool run_colour = colour.tape_form == TAPE_FORM_HIT_VALUE || colour.tape_form == TAPE_FORM_HIT_RGB || product; // the interpreter runs its hit part; everything else is looked up by the replay
                 // job 0: the probability program in full (it is evaluated for the hero wavelength only); job 1: the colour program's
                 // instructions that do not depend on the wavelength -- all of a HIT_VALUE program, all but the closing one of a HIT_RGB
                 for (uint32_t job = c_probability >= 0 ? 0u : 1u; job < 2u; ++job) {
                     if (job == 1u && !run_colour) break;
-                    const uint32_t id = job == 0u ? (uint32_t)c_probability : (product ? colour.tape_hit_program : c_color);
+                    uint32_t id = job == 0u ? (uint32_t)c_probability : c_color;
+                    if constexpr (PRODUCT) id = (job == 1u && product) ? (colour.tape_rgb_reg & 255u) : id; // DevProgram::tape_rgb_reg of a PRODUCT program
                     const DevProgram prog = S.programs[id];
                     const bool interpreted = prog.kind != PYR_PROGRAM_CONSTANT && prog.fast == FAST_NONE;
                     float v;
@@ -2453,11 +2460,12 @@ struct Walker {
                 } else if (colour.tape_form == TAPE_FORM_HIT_VALUE) {
                     tape_push_raw(L, flags | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), hit_value * factor); // value * factor is the product contribute forms
                 } else if (product) { // t = value[slot of the wavelength side] * h1, t = t * h2 ...: the program's products in its order; then t * factor
-                    const uint32_t slot = tape_prepared != nullptr ? tape_prepared[8 * colour.tape_lambda_program + 7] : kTapeOneSlot; // (a hit-tape scene always replays eagerly: api.cpp)
-                    const uint32_t hero = c_companions ? 0u : TAPE_HERO_ONLY, factors = colour.tape_chain & 15u;
-                    tape_push_raw(L, hero | TAPE_RGB_FIRST | (slot << TAPE_EAGER_SLOT_SHIFT), vm.num[(colour.tape_chain >> 4) & 15u]);
+                    const uint32_t packed = colour.tape_rgb_reg;
+                    const uint32_t slot = tape_prepared != nullptr ? tape_prepared[8 * ((packed >> 8) & 255u) + 7] : kTapeOneSlot; // (a hit-tape scene always replays eagerly: api.cpp)
+                    const uint32_t hero = c_companions ? 0u : TAPE_HERO_ONLY, factors = (packed >> 16) & 15u;
+                    tape_push_raw(L, hero | TAPE_RGB_FIRST | (slot << TAPE_EAGER_SLOT_SHIFT), vm.num[(packed >> 20) & 15u]);
                     for (uint32_t k = 1; k < factors; ++k)
-                        tape_push_raw(L, hero | TAPE_RGB_TIMES | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), vm.num[(colour.tape_chain >> (4u + 4u * k)) & 15u]);
+                        tape_push_raw(L, hero | TAPE_RGB_TIMES | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), vm.num[(packed >> (20u + 4u * k)) & 15u]);
                     tape_push_raw(L, flags | TAPE_RGB_APPLY | (kTapeOneSlot << TAPE_EAGER_SLOT_SHIFT), factor);
                 } else { // HIT_RGB: c0 * basis_r + c1 * basis_g + c2 * basis_b (execution_context.rs:140-152), then times the factor
                     const float* c = vm.rgb[colour.tape_rgb_reg & (PYR_MAX_VECTOR_REGISTERS - 1)];
@@ -2797,7 +2805,7 @@ DEV float lambda_eval(const DevScene& S, const DevProgram& p, float wavelength) 
 // exposes its hero only (simple.rs:133-139); a light sample whose material reads the wavelength is added for the hero only
 // (algorithm.rs:78). Consecutive records of one program (the light samples of one estimation) share one look-up, as in the
 // synchronous walk. Must be called by every lane of the wave.
-template <bool COUNT, bool RGB = false> // RGB: the scene may hold HIT_RGB records (interpreter builds that record a tape)
+template <bool COUNT, bool RGB = false, bool TIMES = false> // RGB: the scene may hold HIT_RGB records (interpreter builds that record a tape); TIMES: and PRODUCT ones
 DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, uint32_t n_ops, uint32_t tape_column, const Path& p, const float* wl_rows,
                       uint32_t wl_column, uint32_t* wave_list, const uint32_t* prepared_lds, float* spectral_values, uint32_t n_spectral, bool eager, Counters& cnt) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -2945,13 +2953,16 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                 float values[ROWS];
 #pragma unroll
                 for (uint32_t j = 0; j < ROWS; ++j) values[j] = spectral_values[words[j] & TAPE_EAGER_SLOT_MASK]; // slot << 8 is slot * BLOCK
-                if (RGB && S.micro_records != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it; PRODUCT: one and one
+                if (RGB && (TIMES ? S.micro_records : S.rgb_records) != 0) { // (uniform) HIT_RGB contributions: three coefficient records build the sum, the fourth applies it; PRODUCT: one to three and one
                     const uint32_t not_mine = hero ? 0u : TAPE_HERO_ONLY;
 #pragma unroll
                     for (uint32_t j = 0; j < ROWS; ++j) {
                         const float m = values[j] * factors[j];
-                        const uint32_t op = (words[j] >> TAPE_RGB_SHIFT) & 7u;
-                        rgb_sum = op == 1u ? m : (op == 2u ? rgb_sum + m : (op == 4u ? rgb_sum * m : rgb_sum));
+                        const uint32_t op = (words[j] >> TAPE_RGB_SHIFT) & (TIMES ? 7u : 3u);
+                        if constexpr (TIMES)
+                            rgb_sum = op == 1u ? m : (op == 2u ? rgb_sum + m : (op == 4u ? rgb_sum * m : rgb_sum));
+                        else
+                            rgb_sum = op == 1u ? m : (op == 2u ? rgb_sum + m : rgb_sum);
                         const float mm = op == 3u ? rgb_sum * factors[j] : m;
                         const bool apply = ((words[j] & not_mine) == 0u) & ((op == 0u) | (op == 3u));
                         const bool adds = (int)words[j] < 0;
@@ -3093,10 +3104,11 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
 #define PYR_SM_WAVES_INTERP 3
 #endif
 constexpr int sm_waves(bool interp, bool /*lds_scene*/, bool /*hit_tape*/) { return interp ? PYR_SM_WAVES_INTERP : PYR_SM_WAVES; }
-template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES, bool HIT_TAPE = false>
+template <bool COUNT, bool INTERP, bool LDS_SCENE, bool LDS_TABLES, bool HIT_TAPE = false, bool PRODUCT = false>
 __global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void render_kernel_sm(DevScene S0, RenderLaunch L) {
     extern __shared__ float lds[];
     static_assert(INTERP || !HIT_TAPE, "HIT_TAPE is a form of the interpreter build");
+    static_assert(HIT_TAPE || !PRODUCT, "PRODUCT is a form of the hit tape (device_scene.h TapeForm)");
     constexpr bool TAPE = !INTERP || HIT_TAPE; // see "Spectral tape"; interpreter builds: scenes whose colour programs all have a tape form
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
@@ -3117,7 +3129,7 @@ __global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void 
     const uint32_t total_waves = gridDim.x * waves_per_block;
     const int phase_lanes = (int)L.sm_phase_lanes, trav_steps = (int)L.sm_trav_steps;
     const int expose_lanes = TAPE ? (int)L.sm_expose_lanes : phase_lanes; // the replay works at full width whatever the count, but has a fixed cost per turn
-    Walker<COUNT, INTERP, TAPE> w;
+    Walker<COUNT, INTERP, TAPE, PRODUCT> w;
     w.chunk = L.chunk_begin + blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     w.tape_prepared = nullptr;
     uint32_t* wave_list = reinterpret_cast<uint32_t*>(lds + SS * BLOCK) + (threadIdx.x & ~63u);
@@ -3162,7 +3174,7 @@ __global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void 
             const DevScene Sp = scene_view(Lp);
             // (without hit-tape forms the replay is eager exactly when it has value slots: one uniform less to keep across the loop)
             if constexpr (TAPE)
-                replay_tapes<COUNT, HIT_TAPE>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral,
+                replay_tapes<COUNT, HIT_TAPE, PRODUCT>(Sp, Lp, w.stage == ST_EXPOSE, w.n_ops, w.tape_column, w.p, lds, threadIdx.x, wave_list, prepared_lds, spectral_values, n_spectral,
                                               HIT_TAPE ? eager : n_spectral != 0, cnt);
             w.expose_and_restart(Sp, Lp, spec, cnt, lane, total_waves);
             PROF_END(0);
@@ -3351,7 +3363,7 @@ __global__ __launch_bounds__(BLOCK, PYR_INTERSECT_WAVES) void intersect_kernel(D
     flush_counters<COUNT>(cnt, L.counters);
 }
 
-#if PYR_TU != 1
+#if PYR_TU_MAIN
 // ------------------------------------------------------------------------------------------------ film development
 // main.rs:315-327: every pixel spectrum -> spectrum_to_xyz (main.rs:352-418, trapezoid rule against the CIE observer
 // tables) -> linear sRGB -> sRGB u8. One thread per pixel; the film is read once (bins * 8 B per pixel), HBM-bound.
@@ -3555,17 +3567,31 @@ static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch
     return bytes;
 }
 
-#endif // PYR_TU != 1
+#endif // PYR_TU_MAIN
 
 using RenderKernel = void (*)(DevScene, RenderLaunch);
 // A scene staged in LDS never has its tables staged too (api.cpp: lds_table_floats is only set for scenes that do not live in
 // LDS), so that combination is never instantiated.
-#if PYR_TU != 0
-// The interpreter builds of the stage scheduler (the synchronous walk is built without the interpreter: a scene with interpreter
-// programs always runs on the stage scheduler, which keeps the interpreter in line). HIT_TAPE: see device_scene.h TapeForm.
-RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tables, bool hit_tape) {
+#if PYR_TU_PRODUCT
+// The hit-tape interpreter builds for scenes with TAPE_FORM_PRODUCT colour programs: builds of their own (Walker::tape_pending says why)
+RenderKernel pick_product_kernel(bool with_counters, bool lds_scene, bool lds_tables) {
     auto pick = [&](auto counters) -> RenderKernel {
         constexpr bool C = decltype(counters)::value;
+        if (lds_scene) return render_kernel_sm<C, true, true, false, true, true>;
+        return lds_tables ? render_kernel_sm<C, true, false, true, true, true> : render_kernel_sm<C, true, false, false, true, true>;
+    };
+    return with_counters ? pick(std::true_type{}) : pick(std::false_type{});
+}
+#else
+RenderKernel pick_product_kernel(bool with_counters, bool lds_scene, bool lds_tables);
+#endif
+#if PYR_TU_INTERP
+// The interpreter builds of the stage scheduler (the synchronous walk is built without the interpreter: a scene with interpreter
+// programs always runs on the stage scheduler, which keeps the interpreter in line). HIT_TAPE: see device_scene.h TapeForm.
+RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tables, bool hit_tape, bool product) {
+    auto pick = [&](auto counters) -> RenderKernel {
+        constexpr bool C = decltype(counters)::value;
+        if (hit_tape && product) return pick_product_kernel(C, lds_scene, lds_tables);
         if (lds_scene) return hit_tape ? render_kernel_sm<C, true, true, false, true> : render_kernel_sm<C, true, true, false>;
         if (hit_tape) return lds_tables ? render_kernel_sm<C, true, false, true, true> : render_kernel_sm<C, true, false, false, true>;
         return lds_tables ? render_kernel_sm<C, true, false, true> : render_kernel_sm<C, true, false, false>;
@@ -3573,18 +3599,18 @@ RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tab
     return with_counters ? pick(std::true_type{}) : pick(std::false_type{});
 }
 #else
-RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tables, bool hit_tape);
+RenderKernel pick_interp_kernel(bool with_counters, bool lds_scene, bool lds_tables, bool hit_tape, bool product);
 #endif
 
-#if PYR_TU != 1
-static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables, bool hit_tape) {
+#if PYR_TU_MAIN
+static RenderKernel pick_kernel(bool sm, bool with_counters, bool interp, bool lds_scene, bool lds_tables, bool hit_tape, bool product) {
 #ifdef PYR_DEV_ONLY_SM // developer builds for reading the ISA (tools/asm_sm.sh): only the kernel the BASELINE meshes run is instantiated
     return render_kernel_sm<false, false, false, true>;
 #endif
 #ifdef PYR_DEV_ONLY_SM_INTERP // ... or only the interpreter build the reference's textures example runs
     return render_kernel_sm<false, true, true, false, true>;
 #endif
-    if (interp) return pick_interp_kernel(with_counters, lds_scene, lds_tables, hit_tape);
+    if (interp) return pick_interp_kernel(with_counters, lds_scene, lds_tables, hit_tape, product);
     auto pick = [&](auto counters) -> RenderKernel {
         constexpr bool C = decltype(counters)::value;
         if (lds_scene) return sm ? render_kernel_sm<C, false, true, false> : render_kernel<C, false, true, false>;
@@ -3619,7 +3645,7 @@ int launch_render(const DevScene& scene, const RenderLaunch& launch_in, bool wit
     const uint32_t chunks = launch.chunk_end - launch.chunk_begin;
     if (chunks == 0) return PYR_OK;
     RenderKernel kernel = pick_kernel(launch.scheduler == 1, with_counters, scene.needs_interpreter != 0, scene_fits_lds(scene), scene.lds_table_floats != 0,
-                                      launch.scheduler == 1 && uses_hit_tape(scene, launch));
+                                      launch.scheduler == 1 && uses_hit_tape(scene, launch), scene.product_records != 0);
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) {
         g_kernel_error = std::string("hipFuncSetAttribute: ") + hipGetErrorString(err);
@@ -3687,11 +3713,11 @@ int launch_intersect(const DevScene& scene, const IntersectLaunch& launch, bool 
     return PYR_OK;
 }
 
-#endif // PYR_TU != 1
+#endif // PYR_TU_MAIN
 
 } // namespace pyr
 
-#if defined(PYR_PHASE_PROFILE) && PYR_TU != 1
+#if defined(PYR_PHASE_PROFILE) && PYR_TU_MAIN
 extern "C" int pyr_debug_phase_profile32(unsigned long long* out32, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(pyr::g_phase_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
