@@ -707,11 +707,10 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
     // holds 1.0, three the RGB basis when a HIT_RGB program exists) must hold every spectrum-reading fast program (counted here
     // without the sharing the kernel finds, so never fewer), and the prepared programs must fit their LDS table (128).
     v.hit_tape = v.rgb_records = v.micro_records = v.product_records = 0;
-    if (needs_interpreter) {
-        bool ok = programs.size() <= 128;
-        // value slots of the replay: one per LAMBDA program and one per DISTINCT fast shape -- programs of the same shape, factor and
-        // spectrum share a slot (kernels.hip prepare_tape_tables `alike`: C3's three white walls are three programs over one spectrum)
-        uint32_t fast_programs = 0;
+    // value slots of the replay: one per LAMBDA program and one per DISTINCT fast shape -- programs of the same shape, factor and
+    // spectrum share a slot (kernels.hip prepare_tape_tables `alike`: C3's three white walls are three programs over one spectrum)
+    uint32_t fast_programs = 0;
+    {
         for (size_t i = 0; i < programs.size(); ++i) {
             const DevProgram& pr = programs[i];
             if (pr.kind != PYR_PROGRAM_INSTRUCTIONS) continue;
@@ -726,6 +725,9 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
                 fast_programs += seen ? 0u : 1u;
             }
         }
+    }
+    if (needs_interpreter) {
+        bool ok = programs.size() <= 128;
         auto colour = [&](uint32_t id) {
             if (id >= programs.size()) return;
             const DevProgram& pr = programs[id];
@@ -738,12 +740,14 @@ int pack_and_upload(const PyrSceneDesc* d, PyrScene* s) {
         for (uint32_t i = 0; i < d->num_components; ++i) colour(d->components[i].color_program);
         for (const DevLamp& l : lamps) colour(l.color_program);
         colour(d->sky_program);
-        if (fast_programs + (v.rgb_records ? 3u : 0u) > 7u) ok = false;
+        if (tape_rows_needed(fast_programs, v.rgb_records != 0) > kTapeMaxValueRows) ok = false; // (counted here without LAMBDA's hit-tape condition: never fewer than the kernel finds)
         const char* off = std::getenv("PYRITE_HIT_TAPE"); // A/B and tests: PYRITE_HIT_TAPE=0 keeps the online form (read at scene creation)
         if (off && off[0] == '0') ok = false;
         v.hit_tape = ok ? 1u : 0u;
         if (!ok) v.rgb_records = v.micro_records = v.product_records = 0u;
     }
+    // the eager replay's value rows (device_scene.h): eight, or what the scene's programs need; past sixteen the replay looks values up record by record
+    v.tape_value_rows = tape_rows_needed(fast_programs, v.rgb_records != 0) <= kTapeMaxValueRows ? tape_rows_needed(fast_programs, v.rgb_records != 0) : kTapeValueRows;
     v.shadow_margin = d->num_spheres != 0 ? 1.01f : 1.001f; // device_scene.h
     v.hero_only_records = 0;
     for (uint32_t i = 0; i < d->num_materials; ++i)

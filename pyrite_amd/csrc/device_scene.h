@@ -150,7 +150,23 @@ struct DevScene {
     // sphere routine loses every digit of l.l - tca^2 for a ray that passes at a thousand radii or more and then reports hits up to a
     // radius NEARER than the sphere's own box, which the reference, walking with closest = inf, still counts as blockers.
     float shadow_margin;
+    uint32_t tape_value_rows; // LDS value rows of the eager replay (above): 8, or as many as the scene's spectrum-reading programs need, up to 16
 };
+
+// Value rows of the eager replay (kernels.hip replay_tapes): rows of BLOCK floats in LDS, one per spectrum-reading program -- its value at the
+// replay item's wavelength, looked up once per item -- and one that holds 1.0 (row 7: what the records of constants and plain factors name).
+// Eight rows serve every BASELINE scene (four programs); a scene with more such programs than the seven rows in front of the 1.0 gets more
+// rows behind it, up to the sixteen a record's 4-bit slot field can name (DevScene::tape_value_rows): slot s lives in row s, or s + 1 from
+// the seventh on; the three rows of the RGB basis stay together. (C3 with six more spectra, past the rows: 573 -> 508 Msamples/s looking
+// values up record by record -- tools/bench_many_spectra.py.)
+constexpr uint32_t kTapeValueRows = 8, kTapeOneRow = kTapeValueRows - 1, kTapeMaxValueRows = 16;
+constexpr uint32_t tape_row(uint32_t slot) { return slot + (slot >= kTapeOneRow ? 1u : 0u); }
+constexpr uint32_t tape_rgb_row(uint32_t n_spectral) { return n_spectral + 3u <= kTapeOneRow ? n_spectral : (n_spectral >= kTapeOneRow ? n_spectral + 1u : kTapeValueRows); }
+constexpr uint32_t tape_rows_needed(uint32_t n_spectral, bool rgb) {
+    return (rgb ? tape_rgb_row(n_spectral) + 3u : (n_spectral == 0u ? 0u : tape_row(n_spectral - 1u) + 1u)) > kTapeValueRows
+               ? (rgb ? tape_rgb_row(n_spectral) + 3u : tape_row(n_spectral - 1u) + 1u)
+               : kTapeValueRows;
+}
 
 constexpr uint32_t kMaxStackDepth = 64; // >= kMaxBvhDepth (bvh.h) and >= the wide tree's stack need (else the binary tree is walked)
 

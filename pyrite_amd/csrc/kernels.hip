@@ -2253,6 +2253,7 @@ constexpr uint32_t TAPE_MUL = 0u, TAPE_ADD = 1u, TAPE_SCALE = 2u, TAPE_HERO_ONLY
 // plain factor: both name the slot that holds 1.0 (x * 1.0 is x, bit for bit), so the replay has one straight-line form.
 constexpr uint32_t TAPE_EAGER_ADD = 1u << 31, TAPE_EAGER_SLOT_SHIFT = 8, TAPE_EAGER_SLOT_MASK = 0xFu << TAPE_EAGER_SLOT_SHIFT;
 constexpr uint32_t kTapeOneSlot = kTapeEagerSlots - 1; // the value row that holds 1.0
+static_assert(kTapeEagerSlots == kTapeValueRows && kTapeOneSlot == kTapeOneRow, "device_scene.h tape_row() and friends");
 // Eager records of a HIT_RGB contribution (device_scene.h TapeForm; scenes with S.rgb_records): bits 12-13 of the word say what the
 // record does with m = value[slot] * s -- 1: t = m (first coefficient times the red basis), 2: t = t + m (green, blue),
 // 3: m = t * s, then applied like any record (the contribution's factor). 0: an ordinary record.
@@ -2914,7 +2915,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                     v = spectrum_eval(sp, data, wl);
                 }
 #endif
-                spectral_values[slot * BLOCK] = (mode == FAST_SPECTRUM || mode == 0xFFu) ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
+                spectral_values[tape_row(slot) * BLOCK] = (mode == FAST_SPECTRUM || mode == 0xFFu) ? v : v * c; // FAST_SPECTRUM_MUL and FAST_MUL_SPECTRUM: v * c is c * v
             }
             if (RGB && S.rgb_records != 0) { // (uniform) the RGB basis at this item's wavelength: RgbSpectrumValue's look-up, execution_context.rs:140-152
                 float resp[3] = {0.0f, 0.0f, 0.0f};
@@ -2934,7 +2935,7 @@ DEV void replay_tapes(const DevScene& S, const RenderLaunch& L, bool exposing, u
                         for (int j = 0; j < 3; ++j) resp[j] = d[3 * b0 + j] * (1.0f - bmix) + d[3 * (b0 + 1) + j] * bmix;
                     }
                 }
-                for (uint32_t j = 0; j < 3; ++j) spectral_values[(n_spectral + j) * BLOCK] = resp[j];
+                for (uint32_t j = 0; j < 3; ++j) spectral_values[(tape_rgb_row(n_spectral) + j) * BLOCK] = resp[j];
             }
         }
         for (uint32_t r0 = 0; r0 < pass_ops; r0 += ROWS) {
@@ -3082,16 +3083,15 @@ DEV uint32_t prepare_tape_tables(const DevScene& S0, const DevScene& S, const Re
         const uint32_t slot = spectral ? slot_of(representative) : 0u;
         uint32_t* e = prepared_lds + 8 * i;
         e[0] = q.mode, e[1] = __float_as_uint(q.c), e[2] = q.sp.format, e[3] = __float_as_uint(q.sp.min), e[4] = __float_as_uint(q.sp.max);
-        e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = slot;
-        if (spectral && representative == i && slot < kTapeOneSlot) prepared_lds[8 * L.tape_programs_lds + slot] = i;
+        e[5] = q.sp.offset, e[6] = q.sp.count, e[7] = tape_row(slot); // what a record carries: the value ROW
+        if (spectral && representative == i && slot < kTapeMaxValueRows - 1u) prepared_lds[8 * L.tape_programs_lds + slot] = i;
     }
     __syncthreads();
     // The value rows (the last one holds 1.0; a scene with HIT_RGB programs keeps the RGB basis in three of them, behind the
     // programs' slots): too many spectrum-reading programs for them and the replay looks values up record by record. A scene
     // without any such program has nothing to look up eagerly -- unless it records hit-tape forms, which only the eager replay knows
     // (api.cpp makes sure they fit).
-    const uint32_t needed = n_spectral + (S0.rgb_records != 0 ? 3u : 0u);
-    eager = L.tape_programs_lds != 0 && needed <= kTapeOneSlot && (n_spectral != 0 || S0.hit_tape != 0);
+    eager = L.tape_programs_lds != 0 && tape_rows_needed(n_spectral, S0.rgb_records != 0) <= S0.tape_value_rows && (n_spectral != 0 || S0.hit_tape != 0);
     return eager ? n_spectral : 0u;
 }
 
@@ -3113,7 +3113,7 @@ __global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void 
     const uint32_t SS = L.spectrum_samples;
     Spectral spec{lds + threadIdx.x, SS};
     // LDS rows of 256 floats: TAPE: S wavelengths + one row of per-wave lane lists; else wavelengths / brightness / reflectance
-    const uint32_t spectral_rows = TAPE ? SS + 1 + kTapeEagerSlots : 3 * SS;
+    const uint32_t spectral_rows = TAPE ? SS + 1 + S0.tape_value_rows : 3 * SS;
     TravStack stack;
     int deep_levels[LDS_SCENE ? 1 : kMaxStackDepth]; // a scene that lives in LDS has its whole stack there (launch_render)
     stack.deep = deep_levels;
@@ -3146,7 +3146,7 @@ __global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void 
         spectral_values[kTapeOneSlot * BLOCK] = 1.0f;
         n_spectral = prepare_tape_tables(S0, S, L, prepared_lds, eager);
         if (eager) w.tape_prepared = prepared_lds;
-        w.rgb_slot = n_spectral;
+        w.rgb_slot = tape_rgb_row(n_spectral);
         w.tape_column = blockIdx.x * BLOCK + threadIdx.x;
         if (HIT_TAPE && !eager) *L.tape_overflow = 1u; // api.cpp only marks a scene hit_tape when its value slots fit: never taken
     }
@@ -3154,7 +3154,7 @@ __global__ __launch_bounds__(BLOCK, sm_waves(INTERP, LDS_SCENE, HIT_TAPE)) void 
     // the scene record as the phases see it (table pointers at the staged copies), rebuilt where a phase starts
     auto scene_view = [&](const RenderLaunch& Lp) {
         if (!PYR_RELOAD_LAUNCH || LDS_SCENE || INTERP) return S; // interpreter builds hand the record to run_interpreter by address: one copy in scratch, made once
-        const uint32_t rows = (TAPE ? Lp.spectrum_samples + 1 + kTapeEagerSlots : 3 * Lp.spectrum_samples) + Lp.stack_lds;
+        const uint32_t rows = (TAPE ? Lp.spectrum_samples + 1 + S0.tape_value_rows : 3 * Lp.spectrum_samples) + Lp.stack_lds;
         return stage_tables<LDS_TABLES ? 1 : 0, false>(scene_from_kernarg(S0), lds, rows * BLOCK);
     };
     PROF_DECL;
@@ -3559,11 +3559,11 @@ static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) {
     return launch.scheduler == 1 && (scene.needs_interpreter == 0 || uses_hit_tape(scene, launch));
 }
 static size_t render_lds_bytes(const DevScene& scene, const RenderLaunch& launch) {
-    const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + kTapeEagerSlots : 3 * launch.spectrum_samples;
+    const size_t spectral_rows = uses_tape(scene, launch) ? launch.spectrum_samples + 1 + scene.tape_value_rows : 3 * launch.spectrum_samples;
     size_t bytes = (spectral_rows + launch.stack_lds) * BLOCK * sizeof(float);
     if (scene_fits_lds(scene)) bytes += (size_t)scene.num_nodes * 64 + (size_t)scene.num_prims * 48;
     bytes += (size_t)scene.lds_table_floats * sizeof(float);
-    if (uses_tape(scene, launch)) bytes += ((size_t)tape_programs_in_lds(scene) * 8 + kTapeEagerSlots) * sizeof(uint32_t);
+    if (uses_tape(scene, launch)) bytes += ((size_t)tape_programs_in_lds(scene) * 8 + kTapeMaxValueRows) * sizeof(uint32_t);
     return bytes;
 }
 
