@@ -3554,7 +3554,10 @@ constexpr uint32_t kTapeProgramsLds = 128; // prepared programs kept in LDS for 
 static uint32_t tape_programs_in_lds(const DevScene& scene) { return scene.num_programs <= kTapeProgramsLds ? scene.num_programs : 0u; }
 // Interpreter scenes record a tape when their colour programs allow it (DevScene::hit_tape) and there are wavelengths to share a
 // hit's work among: with one or two per sample the online form wins (diamonds.lua, one wavelength, 256 bounces: 538 against 486).
-bool uses_hit_tape(const DevScene& scene, const RenderLaunch& launch) { return scene.needs_interpreter != 0 && scene.hit_tape != 0 && launch.spectrum_samples >= 4; }
+bool uses_hit_tape(const DevScene& scene, const RenderLaunch& launch) {
+    static const char* const least = std::getenv("PYRITE_HIT_TAPE_WAVELENGTHS"); // development: the fewest wavelengths per sample a hit tape is recorded for
+    return scene.needs_interpreter != 0 && scene.hit_tape != 0 && launch.spectrum_samples >= (least && *least ? (uint32_t)std::strtoul(least, nullptr, 10) : 4u);
+}
 static bool uses_tape(const DevScene& scene, const RenderLaunch& launch) {
     return launch.scheduler == 1 && (scene.needs_interpreter == 0 || uses_hit_tape(scene, launch));
 }
