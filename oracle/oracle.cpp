@@ -1815,7 +1815,7 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
         if (dbg) { // the sample's shadow rays are printed as they are traced (trace_direct), blocked ones too
             unsigned dx = 0, dy = 0;
             uint64_t qx, qy;
-            g_debug_shadow_rays = std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy;
+            g_debug_shadow_rays = std::strcmp(dbg, "all") == 0 || (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy);
         }
         trace(s, path, lights, rng, ray, wavelength, p.bounces, p.light_samples, exe, c);
         g_debug_shadow_rays = false;
@@ -1829,7 +1829,7 @@ void render_tile(const OracleScene& s, const Tile& tile, const FilmView& film, c
         if (dbg) { // developer aid: ORACLE_DEBUG_PIXEL=x,y prints the samples of one pixel
             unsigned dx = 0, dy = 0;
             uint64_t qx, qy;
-            if (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy) {
+            if (std::strcmp(dbg, "all") == 0 || (std::sscanf(dbg, "%u,%u", &dx, &dy) == 2 && to_pixel(film.desc.width, film.desc.height, px, py, qx, qy) && qx == dx && qy == dy)) { // ORACLE_DEBUG_PIXEL=all: every sample (small images)
                 std::fprintf(stderr, "[oracle] tile %u iteration %llu hero %.9g nm brightness %.9g use_additional %d bounces %zu\n", tile.raster_index,
                              (unsigned long long)i, main_sample.wavelength, main_sample.brightness, (int)use_additional, path.size());
                 std::fprintf(stderr, "    camera ray origin (%.9g %.9g %.9g) direction (%.9g %.9g %.9g)\n", camera_ray.origin.x, camera_ray.origin.y, camera_ray.origin.z,

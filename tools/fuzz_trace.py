@@ -12,6 +12,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 kind, seed = sys.argv[1], int(sys.argv[2])
 pixel = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else None
+if len(sys.argv) == 4 and sys.argv[3] == "all":  # every ray of every sample of the image (ORACLE_DEBUG_PIXEL=all): a difference the film does not show
+    pixel = "all"                                # (a path counter gave it away): run as  ORACLE_DEBUG_PIXEL=all python tools/fuzz_trace.py KIND SEED all
 
 import oracle
 from pyrite_amd import scenes
